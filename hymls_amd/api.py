@@ -1,0 +1,345 @@
+"""ctypes binding of include/hymls_mi.h and the reference-shaped Python operator.
+
+``Preconditioner`` keeps the reference's method names and lifecycle
+(SetParameters -> Initialize -> Compute -> ApplyInverse*, reference
+src/HYMLS_Preconditioner.hpp:93-127): ``Compute`` auto-initialises, ``ApplyInverse``
+before ``Compute`` is an error (src/HYMLS_Preconditioner.cpp:403-409, 936-939), ``Apply``
+returns -1 (not implemented in the reference either, :585-592).  Parameters use the
+reference's XML key names ("Problem"/"Preconditioner" sublists).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhymls_mi.so")
+
+
+class HymlsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hymls_mi error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nx", "ny", "nz", "dim", "equations", "dof", "sx", "sy", "sz", "cx", "cy", "cz", "levels",
+        "partitioner", "retain_nodes", "retain_pressures", "link_velocities", "link_retained",
+        "fix_pressure_level", "nfix")] + [("fix_gid", C.c_int32 * 4), ("variable_type", C.c_int32 * 8)]
+
+
+_I32P = C.POINTER(C.c_int32)
+_F64P = C.POINTER(C.c_double)
+_libs = {}
+
+
+def load_library(path=None):
+    """Load the C-ABI library.  The product path is hymls_amd/libhymls_mi.so (HIP);
+    tests of the host logic pass the path of the test-only simulator explicitly."""
+    path = os.path.abspath(path or LIB_PATH)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). hymls_amd has no CPU fallback." % path)
+    lib = C.CDLL(path)
+    H = C.c_void_p
+    sig = {
+        "hymls_mi_default_params": (None, [C.POINTER(_Params)]),
+        "hymls_mi_create": (C.c_int, [C.POINTER(H), C.POINTER(_Params), C.c_int]),
+        "hymls_mi_set_matrix_csr": (C.c_int, [H, C.c_int64, _I32P, _I32P, _F64P]),
+        "hymls_mi_set_testvector": (C.c_int, [H, _F64P]),
+        "hymls_mi_initialize": (C.c_int, [H]),
+        "hymls_mi_compute": (C.c_int, [H]),
+        "hymls_mi_apply_inverse": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+        "hymls_mi_apply": (C.c_int, [H, _F64P, _F64P]),
+        "hymls_mi_matvec": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int]),
+        "hymls_mi_is_initialized": (C.c_int, [H]),
+        "hymls_mi_is_computed": (C.c_int, [H]),
+        "hymls_mi_num_initialize": (C.c_int, [H]),
+        "hymls_mi_num_compute": (C.c_int, [H]),
+        "hymls_mi_num_apply_inverse": (C.c_int, [H]),
+        "hymls_mi_initialize_time": (C.c_double, [H]),
+        "hymls_mi_compute_time": (C.c_double, [H]),
+        "hymls_mi_apply_inverse_time": (C.c_double, [H]),
+        "hymls_mi_num_levels": (C.c_int, [H]),
+        "hymls_mi_level_size": (C.c_int64, [H, C.c_int]),
+        "hymls_mi_level_schur_size": (C.c_int64, [H, C.c_int]),
+        "hymls_mi_level_num_subdomains": (C.c_int64, [H, C.c_int]),
+        "hymls_mi_apply_bytes": (C.c_double, [H, C.c_int]),
+        "hymls_mi_last_apply_seconds": (C.c_double, [H, C.c_int]),
+        "hymls_mi_set_profiling": (C.c_int, [H, C.c_int]),
+        "hymls_mi_stream": (C.c_void_p, [H]),
+        "hymls_mi_get_interior": (C.c_int, [H, C.c_int, C.c_int, _I32P, _I32P]),
+        "hymls_mi_get_separator_groups": (C.c_int, [H, C.c_int, C.c_int, _I32P, _I32P, _I32P, _I32P, _I32P]),
+        "hymls_mi_generate_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                               C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I32P, _I32P, _F64P]),
+        "hymls_mi_generate_testvector": (C.c_int, [C.c_int64, _I32P, _I32P, _F64P, _F64P]),
+        "hymls_mi_last_error": (C.c_char_p, [H]),
+        "hymls_mi_destroy": (None, [H]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        f.restype = res
+        f.argtypes = args
+    lib._hymls_symbols = sorted(sig)
+    _libs[path] = lib
+    return lib
+
+
+def _i32(a):
+    return a.ctypes.data_as(_I32P)
+
+
+def _f64(a):
+    return a.ctypes.data_as(_F64P)
+
+
+def generate_matrix(equations, nx, ny, nz, a=None, b=1.0, lib=None):
+    """CSR arrays (rowptr, colind, val) of the synthetic benchmark matrices:
+    'Laplace' (Galeri Laplace3D scaled by -1) or 'Stokes-C' (GaleriExt::Stokes3D with
+    a = nx^2, b = 1 by default, reference src/HYMLS_MainUtils.cpp:260-348)."""
+    lib = lib or load_library()
+    eq = {"Laplace": 0, "Stokes-C": 1}[equations]
+    if a is None:
+        a = float(nx * nx)
+    n, nnz = C.c_int64(), C.c_int64()
+    ierr = lib.hymls_mi_generate_matrix(eq, nx, ny, nz, a, b, C.byref(n), C.byref(nnz), None, None, None)
+    if ierr:
+        raise HymlsError(ierr, "generate_matrix")
+    rowptr = np.empty(n.value + 1, np.int32)
+    col = np.empty(nnz.value, np.int32)
+    val = np.empty(nnz.value, np.float64)
+    lib.hymls_mi_generate_matrix(eq, nx, ny, nz, a, b, C.byref(n), C.byref(nnz), _i32(rowptr), _i32(col), _f64(val))
+    return rowptr, col, val
+
+
+def generate_testvector(rowptr, col, val, lib=None):
+    lib = lib or load_library()
+    tv = np.empty(rowptr.size - 1, np.float64)
+    lib.hymls_mi_generate_testvector(rowptr.size - 1, _i32(rowptr), _i32(col), _f64(val), _f64(tv))
+    return tv
+
+
+_EQ = {"Laplace": 0, "Stokes-C": 1}
+_PART = {"Cartesian": 0, "Skew Cartesian": 1}
+_VT = {"Laplace": 0, "Velocity U": 1, "Velocity V": 2, "Velocity W": 3, "Pressure": 4, "Interior": 5}
+
+
+class Preconditioner:
+    """HYMLS::Preconditioner(K, params, testVector) on one MI355X.
+
+    K       : (rowptr, colind, val) CSR arrays or a scipy.sparse matrix, rows in GID order
+    params  : dict with the reference's sublists, e.g.
+              {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": 32, "ny": 32, "nz": 32},
+               "Preconditioner": {"Separator Length": 8, "Number of Levels": 1, "Partitioner": "Cartesian"}}
+    """
+
+    def __init__(self, K, params, testVector=None, device=0, lib=None):
+        self._lib = load_library(lib) if (lib is None or isinstance(lib, str)) else lib
+        self._h = C.c_void_p()
+        self._params = params
+        p = _Params()
+        self._lib.hymls_mi_default_params(C.byref(p))
+        self._fill(p, params)
+        ierr = self._lib.hymls_mi_create(C.byref(self._h), C.byref(p), device)
+        self._check(ierr)
+        self._n = None
+        self.SetMatrix(K)
+        if testVector is not None:
+            tv = np.ascontiguousarray(testVector, dtype=np.float64)
+            self._check(self._lib.hymls_mi_set_testvector(self._h, _f64(tv)))
+
+    @staticmethod
+    def _fill(p, params):
+        prob = params.get("Problem", {})
+        prec = params.get("Preconditioner", {})
+        p.dim = prob.get("Dimension", 3)
+        p.nx = prob.get("nx", -1)
+        p.ny = prob.get("ny", -1)
+        p.nz = prob.get("nz", -1)
+        if "Equations" in prob:
+            if prob["Equations"] not in _EQ:
+                raise HymlsError(-2, "'Equations' parameter not recognized")
+            p.equations = _EQ[prob["Equations"]]
+        else:
+            p.equations = -1
+            p.dof = prob.get("Degrees of Freedom", 1)
+            for d in range(p.dof):
+                vt = prob.get("Variable %d" % d, {}).get("Variable Type", "Laplace")
+                if vt == "Velocity":
+                    vt = "Velocity " + "UVW"[sum(1 for e in range(d) if prob.get("Variable %d" % e, {}).get(
+                        "Variable Type", "Laplace").startswith("Velocity"))]
+                p.variable_type[d] = _VT[vt]
+        p.sx = prec.get("Separator Length (x)", prec.get("Separator Length", 4))
+        p.sy = prec.get("Separator Length (y)", prec.get("Separator Length", -1))
+        p.sz = prec.get("Separator Length (z)", prec.get("Separator Length", -1))
+        p.cx = prec.get("Coarsening Factor (x)", prec.get("Coarsening Factor", -1))
+        p.cy = prec.get("Coarsening Factor (y)", prec.get("Coarsening Factor", -1))
+        p.cz = prec.get("Coarsening Factor (z)", prec.get("Coarsening Factor", -1))
+        p.levels = prec.get("Number of Levels", 1)
+        p.partitioner = _PART[prec.get("Partitioner", "Cartesian")]
+        p.retain_nodes = prec.get("Retain Nodes", -1)
+        p.retain_pressures = prob.get("Retained Pressure Nodes", -1)
+        p.link_velocities = int(prec.get("Eliminate Velocities Together", True))
+        p.link_retained = int(prec.get("Eliminate Retained Nodes Together", True))
+        p.fix_pressure_level = int(prec.get("Fix Pressure Level", True))
+        fix = []
+        k = 1
+        while ("Fix GID %d" % k) in prec:
+            fix.append(prec["Fix GID %d" % k])
+            k += 1
+        p.nfix = len(fix)
+        for i, g in enumerate(fix[:4]):
+            p.fix_gid[i] = g
+        variant = prec.get("Preconditioner Variant", "Block Diagonal")
+        if variant != "Block Diagonal":
+            raise HymlsError(-99, "Variant '%s' not implemented" % variant)
+
+    def _check(self, ierr):
+        if ierr != 0:
+            raise HymlsError(ierr, self._lib.hymls_mi_last_error(self._h).decode())
+
+    # --- reference API
+    def SetMatrix(self, K):
+        if hasattr(K, "tocsr"):
+            K = K.tocsr()
+            K.sort_indices()
+            K = (K.indptr, K.indices, K.data)
+        rowptr = np.ascontiguousarray(K[0], dtype=np.int32)
+        col = np.ascontiguousarray(K[1], dtype=np.int32)
+        val = np.ascontiguousarray(K[2], dtype=np.float64)
+        self._n = rowptr.size - 1
+        self._check(self._lib.hymls_mi_set_matrix_csr(self._h, self._n, _i32(rowptr), _i32(col), _f64(val)))
+        return 0
+
+    def Initialize(self):
+        self._check(self._lib.hymls_mi_initialize(self._h))
+        return 0
+
+    def Compute(self):
+        self._check(self._lib.hymls_mi_compute(self._h))
+        return 0
+
+    def IsInitialized(self):
+        return bool(self._lib.hymls_mi_is_initialized(self._h))
+
+    def IsComputed(self):
+        return bool(self._lib.hymls_mi_is_computed(self._h))
+
+    def ApplyInverse(self, B, X=None):
+        """X = P^{-1} B.  numpy arrays (n,) or (n, nvec) column-major semantics; or torch
+        CUDA tensors (float64, contiguous columns) for the device-resident path."""
+        if hasattr(B, "data_ptr"):  # torch tensor on the device
+            import torch
+            if X is None:
+                X = torch.empty_like(B)
+            nvec = 1 if B.dim() == 1 else B.shape[0]
+            # device multivectors are stored as (nvec, n) row-major = column-major (n, nvec)
+            assert B.dtype == torch.float64 and B.is_contiguous() and X.is_contiguous()
+            self._check(self._lib.hymls_mi_apply_inverse(self._h, B.data_ptr(), self._n, X.data_ptr(), self._n, nvec, 1))
+            return X
+        Bc = np.asfortranarray(np.asarray(B, dtype=np.float64))
+        Xc = np.empty_like(Bc, order="F")
+        nvec = 1 if Bc.ndim == 1 else Bc.shape[1]
+        self._check(self._lib.hymls_mi_apply_inverse(self._h, Bc.ctypes.data, self._n, Xc.ctypes.data, self._n, nvec, 0))
+        if X is not None:
+            X[...] = Xc
+            return X
+        return Xc
+
+    def Apply(self, X, Y):
+        return -1  # not implemented in the reference either
+
+    def MatVec(self, X, Y=None):
+        if hasattr(X, "data_ptr"):
+            import torch
+            if Y is None:
+                Y = torch.empty_like(X)
+            self._check(self._lib.hymls_mi_matvec(self._h, X.data_ptr(), Y.data_ptr(), 1))
+            return Y
+        Xc = np.ascontiguousarray(X, dtype=np.float64)
+        Yc = np.empty_like(Xc)
+        self._check(self._lib.hymls_mi_matvec(self._h, Xc.ctypes.data, Yc.ctypes.data, 0))
+        return Yc
+
+    def SetUseTranspose(self, flag):
+        return -1
+
+    def UseTranspose(self):
+        return False
+
+    def HasNormInf(self):
+        return False
+
+    def Condest(self):
+        return -1.0
+
+    def Label(self):
+        return "Preconditioner"
+
+    def NumInitialize(self):
+        return self._lib.hymls_mi_num_initialize(self._h)
+
+    def NumCompute(self):
+        return self._lib.hymls_mi_num_compute(self._h)
+
+    def NumApplyInverse(self):
+        return self._lib.hymls_mi_num_apply_inverse(self._h)
+
+    def InitializeTime(self):
+        return self._lib.hymls_mi_initialize_time(self._h)
+
+    def ComputeTime(self):
+        return self._lib.hymls_mi_compute_time(self._h)
+
+    def ApplyInverseTime(self):
+        return self._lib.hymls_mi_apply_inverse_time(self._h)
+
+    # --- measurement / introspection
+    def level_sizes(self):
+        n = self._lib.hymls_mi_num_levels(self._h)
+        return [(l, self._lib.hymls_mi_level_size(self._h, l), self._lib.hymls_mi_level_schur_size(self._h, l),
+                 self._lib.hymls_mi_level_num_subdomains(self._h, l)) for l in range(n)]
+
+    def apply_bytes(self, which=0):
+        return self._lib.hymls_mi_apply_bytes(self._h, which)
+
+    def set_profiling(self, on=True):
+        self._lib.hymls_mi_set_profiling(self._h, int(on))
+
+    def last_apply_seconds(self, which=0):
+        return self._lib.hymls_mi_last_apply_seconds(self._h, which)
+
+    def stream(self):
+        return self._lib.hymls_mi_stream(self._h)
+
+    def interior(self, level, sd):
+        n = C.c_int32()
+        self._check(self._lib.hymls_mi_get_interior(self._h, level, sd, C.byref(n), None))
+        out = np.empty(n.value, np.int32)
+        self._lib.hymls_mi_get_interior(self._h, level, sd, C.byref(n), _i32(out))
+        return out
+
+    def separator_groups(self, level, sd):
+        """[(type, owned, nodes)] of every separator group around subdomain sd."""
+        ng = C.c_int32()
+        self._check(self._lib.hymls_mi_get_separator_groups(self._h, level, sd, C.byref(ng), None, None, None, None))
+        gptr = np.zeros(ng.value + 1, np.int32)
+        self._lib.hymls_mi_get_separator_groups(self._h, level, sd, C.byref(ng), _i32(gptr), None, None, None)
+        gtype = np.empty(ng.value, np.int32)
+        owned = np.empty(ng.value, np.int32)
+        nodes = np.empty(max(int(gptr[-1]), 1), np.int32)
+        self._lib.hymls_mi_get_separator_groups(self._h, level, sd, C.byref(ng), _i32(gptr), _i32(gtype), _i32(owned), _i32(nodes))
+        return [(int(gtype[g]), bool(owned[g]), nodes[gptr[g]:gptr[g + 1]].copy()) for g in range(ng.value)]
+
+    def close(self):
+        if self._h:
+            self._lib.hymls_mi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,338 @@
+// capi.cpp -- the C ABI of include/hymls_mi.h on top of LevelSolver.
+#include "../../include/hymls_mi.h"
+#include "precond.hpp"
+#include <chrono>
+#include <cstring>
+
+namespace hymls {
+int64_t generate_laplace3d(int nx, int ny, int nz, int32_t* rowptr, int32_t* col, double* val);
+int64_t generate_stokes3d(int nx, int ny, int nz, double a, double b, int32_t* rowptr, int32_t* col, double* val);
+}
+
+using namespace hymls;
+
+struct hymls_mi {
+  Params p;
+  int device = 0;
+  Csr K;
+  bool have_matrix = false;
+  dvec tv;
+  std::unique_ptr<LevelSolver> top;
+  bool initialized = false, computed = false;
+  int n_init = 0, n_comp = 0, n_apply = 0;
+  double t_init = 0, t_comp = 0, t_apply = 0;
+  std::string err;
+  double *d_b = nullptr, *d_x = nullptr;
+  int64_t buf_n = 0;
+  bool profiling = false;
+};
+
+static double now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+#define API_BEGIN try {
+#define API_END(h)                                                   \
+  }                                                                  \
+  catch (const hymls::Error& e) { if (h) (h)->err = e.what(); return e.code; } \
+  catch (const std::exception& e) { if (h) (h)->err = e.what(); return -3; }   \
+  return 0;
+
+extern "C" {
+
+void hymls_mi_default_params(hymls_mi_params* p) {
+  std::memset(p, 0, sizeof *p);
+  p->nx = p->ny = p->nz = -1;
+  p->dim = 3; p->equations = 0; p->dof = -1;
+  p->sx = 4; p->sy = p->sz = -1; p->cx = p->cy = p->cz = -1;
+  p->levels = 1; p->partitioner = 0; p->retain_nodes = -1; p->retain_pressures = -1;
+  p->link_velocities = 1; p->link_retained = 1; p->fix_pressure_level = 1; p->nfix = 0;
+}
+
+static Params convert(const hymls_mi_params* q) {
+  // defaults as BasePartitioner::SetParameters (reference src/HYMLS_BasePartitioner.cpp:31-252)
+  Params p;
+  p.dim = q->dim;
+  p.nx = q->nx; p.ny = q->ny < 0 ? q->nx : q->ny;
+  p.nz = q->nz < 0 ? (q->dim > 2 ? q->nx : 1) : q->nz;
+  HYMLS_CHECK(p.nx > 0, -2, "You must presently specify nx, ny (and possibly nz)");
+  p.sx = q->sx; p.sy = q->sy < 0 ? p.sx : q->sy; p.sz = p.nz > 1 ? (q->sz < 0 ? p.sx : q->sz) : 1;
+  HYMLS_CHECK(p.sx > 1, -2, "Separator Length not set correctly");
+  p.cx = q->cx < 0 ? p.sx : q->cx; p.cy = q->cy < 0 ? p.cx : q->cy; p.cz = p.nz > 1 ? (q->cz < 0 ? p.cx : q->cz) : 1;
+  HYMLS_CHECK(p.cx > 1, -2, "Coarsening Factor not set correctly");
+  p.rx = p.ry = p.rz = q->retain_nodes;
+  p.levels = q->levels;
+  p.partitioner = q->partitioner;
+  p.link_velocities = q->link_velocities != 0; p.link_retained = q->link_retained != 0;
+  p.retain_pressures = q->retain_pressures < 0 ? 1 : q->retain_pressures;
+  if (q->equations == 0) {
+    p.dof = 1; p.vtype = {VT_LAPLACE};
+  } else if (q->equations == 1) {
+    p.dof = p.dim + 1;
+    p.vtype = p.dim == 2 ? std::vector<int32_t>{VT_U, VT_V, VT_P} : std::vector<int32_t>{VT_U, VT_V, VT_W, VT_P};
+    if (q->fix_pressure_level) p.fix_gid = {p.dim};
+  } else {
+    HYMLS_CHECK(q->dof > 0 && q->dof <= 8, -2, "'Equations' parameter not recognized and no 'Degrees of Freedom' given");
+    p.dof = q->dof;
+    p.vtype.assign(q->variable_type, q->variable_type + q->dof);
+  }
+  if (q->nfix > 0) p.fix_gid.assign(q->fix_gid, q->fix_gid + std::min(q->nfix, 4));
+  return p;
+}
+
+int hymls_mi_create(hymls_mi_t** out, const hymls_mi_params* q, int device) {
+  if (!out || !q) return -2;
+  hymls_mi* h = new hymls_mi();
+  *out = h;
+  API_BEGIN
+  h->p = convert(q);
+  h->device = device;
+  dev::init(device);
+  API_END(h)
+}
+
+int hymls_mi_set_matrix_csr(hymls_mi_t* h, int64_t n, const int32_t* rowptr, const int32_t* colind, const double* val) {
+  if (!h) return -2;
+  API_BEGIN
+  const int64_t N = (int64_t)h->p.nx * h->p.ny * h->p.nz * h->p.dof;
+  HYMLS_CHECK(n == N, -2, "matrix size does not match nx*ny*nz*dof");
+  const int64_t nnz = rowptr[n];
+  const bool same = h->have_matrix && h->K.n == n && (int64_t)h->K.col.size() == nnz &&
+                    std::memcmp(h->K.rowptr.data(), rowptr, (n + 1) * 4) == 0 &&
+                    std::memcmp(h->K.col.data(), colind, nnz * 4) == 0;
+  h->K.n = (int32_t)n;
+  h->K.rowptr.assign(rowptr, rowptr + n + 1);
+  h->K.col.assign(colind, colind + nnz);
+  h->K.val.assign(val, val + nnz);
+  h->have_matrix = true;
+  h->computed = false;
+  if (same && h->top) h->top->set_values(h->K.val);   // SetMatrix: pattern reused
+  else { h->top.reset(); h->initialized = false; }
+  API_END(h)
+}
+
+int hymls_mi_set_testvector(hymls_mi_t* h, const double* v) {
+  if (!h) return -2;
+  API_BEGIN
+  HYMLS_CHECK(h->have_matrix, -1, "set the matrix first");
+  h->tv.assign(v, v + h->K.n);
+  h->top.reset(); h->initialized = false; h->computed = false;
+  API_END(h)
+}
+
+int hymls_mi_initialize(hymls_mi_t* h) {
+  if (!h) return -2;
+  API_BEGIN
+  HYMLS_CHECK(h->have_matrix, -1, "no matrix set");
+  const double t0 = now();
+  if (h->tv.empty()) h->tv.assign(h->K.n, 1.0);
+  ivec gids(h->K.n);
+  std::iota(gids.begin(), gids.end(), 0);
+  h->top.reset(new LevelSolver(h->p, 0, h->K, gids, h->tv, (int64_t)h->K.n));
+  h->top->initialize();
+  h->top->profiling = h->profiling;
+  h->initialized = true; h->computed = false;
+  h->n_init++;
+  h->t_init += now() - t0;
+  API_END(h)
+}
+
+int hymls_mi_compute(hymls_mi_t* h) {
+  if (!h) return -2;
+  if (!h->initialized) {  // Preconditioner.cpp:403-409: "I'll do it for you"
+    int ierr = hymls_mi_initialize(h);
+    if (ierr) return ierr;
+  }
+  API_BEGIN
+  const double t0 = now();
+  h->top->compute();
+  dev::sync();
+  h->computed = true;
+  h->n_comp++;
+  h->t_comp += now() - t0;
+  API_END(h)
+}
+
+int hymls_mi_apply_inverse(hymls_mi_t* h, const double* B, int64_t ldb, double* X, int64_t ldx, int nvec, int on_device) {
+  if (!h) return -2;
+  API_BEGIN
+  HYMLS_CHECK(h->computed, -1, "The preconditioner has not yet been computed.");
+  const double t0 = now();
+  const int64_t n = h->K.n;
+  if (!on_device && h->buf_n < n) {
+    dev::free(h->d_b); dev::free(h->d_x);
+    h->d_b = (double*)dev::alloc(n * sizeof(double));
+    h->d_x = (double*)dev::alloc(n * sizeof(double));
+    h->buf_n = n;
+  }
+  for (int k = 0; k < nvec; k++) {
+    if (on_device) {
+      h->top->apply_inverse(B + k * ldb, X + k * ldx);
+    } else {
+      dev::h2d(h->d_b, B + k * ldb, n * sizeof(double));
+      h->top->apply_inverse(h->d_b, h->d_x);
+      dev::d2h(X + k * ldx, h->d_x, n * sizeof(double));
+    }
+  }
+  h->n_apply++;
+  if (!on_device) h->t_apply += now() - t0;
+  API_END(h)
+}
+
+int hymls_mi_apply(hymls_mi_t*, const double*, double*) { return -1; }
+
+int hymls_mi_matvec(hymls_mi_t* h, const double* X, double* Y, int on_device) {
+  if (!h) return -2;
+  API_BEGIN
+  HYMLS_CHECK(h->computed, -1, "matvec needs a computed preconditioner (device copy of K)");
+  const int64_t n = h->K.n;
+  if (on_device) { h->top->matvec(X, Y); }
+  else {
+    if (h->buf_n < n) {
+      dev::free(h->d_b); dev::free(h->d_x);
+      h->d_b = (double*)dev::alloc(n * sizeof(double)); h->d_x = (double*)dev::alloc(n * sizeof(double)); h->buf_n = n;
+    }
+    dev::h2d(h->d_b, X, n * sizeof(double));
+    h->top->matvec(h->d_b, h->d_x);
+    dev::d2h(Y, h->d_x, n * sizeof(double));
+  }
+  API_END(h)
+}
+
+int hymls_mi_is_initialized(const hymls_mi_t* h) { return h && h->initialized; }
+int hymls_mi_is_computed(const hymls_mi_t* h) { return h && h->computed; }
+int hymls_mi_num_initialize(const hymls_mi_t* h) { return h ? h->n_init : 0; }
+int hymls_mi_num_compute(const hymls_mi_t* h) { return h ? h->n_comp : 0; }
+int hymls_mi_num_apply_inverse(const hymls_mi_t* h) { return h ? h->n_apply : 0; }
+double hymls_mi_initialize_time(const hymls_mi_t* h) { return h ? h->t_init : 0; }
+double hymls_mi_compute_time(const hymls_mi_t* h) { return h ? h->t_comp : 0; }
+double hymls_mi_apply_inverse_time(const hymls_mi_t* h) { return h ? h->t_apply : 0; }
+
+static const Operator* level_op(const hymls_mi_t* h, int level, const LevelSolver** ls) {
+  const LevelSolver* L = h->top.get();
+  *ls = L;
+  const Operator* op = L;
+  for (int l = 0; l < level && op; l++) {
+    if (!*ls) return nullptr;
+    op = (*ls)->next();
+    *ls = (*ls)->next_level();
+  }
+  return op;
+}
+
+int hymls_mi_num_levels(const hymls_mi_t* h) {
+  if (!h || !h->top) return 0;
+  int n = 1;
+  const LevelSolver* L = h->top.get();
+  while (L && L->next()) { n++; L = L->next_level(); }
+  return n;
+}
+int64_t hymls_mi_level_size(const hymls_mi_t* h, int level) {
+  if (!h || !h->top) return -1;
+  const LevelSolver* ls; const Operator* op = level_op(h, level, &ls);
+  return op ? op->size() : -1;
+}
+int64_t hymls_mi_level_schur_size(const hymls_mi_t* h, int level) {
+  if (!h || !h->top) return -1;
+  const LevelSolver* ls; const Operator* op = level_op(h, level, &ls);
+  return (op && ls) ? ls->schur_size() : 0;
+}
+int64_t hymls_mi_level_num_subdomains(const hymls_mi_t* h, int level) {
+  if (!h || !h->top) return -1;
+  const LevelSolver* ls; const Operator* op = level_op(h, level, &ls);
+  return (op && ls) ? (int64_t)ls->hiermap().sd.size() : 0;
+}
+
+double hymls_mi_apply_bytes(const hymls_mi_t* h, int which) {
+  if (!h || !h->top) return 0;
+  ApplyStats st;
+  h->top->add_stats(st, false);
+  switch (which) {
+    case 1: return st.bytes_factor;
+    case 2: return st.bytes_spmv;
+    case 3: return st.bytes_sep;
+    case 4: return st.bytes_coarse;
+    case 5: return st.bytes_vec;
+    default: return st.bytes_factor + st.bytes_spmv + st.bytes_sep + st.bytes_coarse + st.bytes_vec;
+  }
+}
+double hymls_mi_last_apply_seconds(const hymls_mi_t* h, int which) {
+  if (!h || !h->top || which < 0 || which > 4) return 0;
+  return h->top->phase_seconds[which];
+}
+int hymls_mi_set_profiling(hymls_mi_t* h, int on) {
+  if (!h) return -2;
+  h->profiling = on != 0;
+  if (h->top) h->top->profiling = h->profiling;
+  return 0;
+}
+void* hymls_mi_stream(const hymls_mi_t*) { return dev::stream(); }
+
+int hymls_mi_get_interior(const hymls_mi_t* h, int level, int sd, int32_t* n, int32_t* nodes) {
+  if (!h || !h->top) return -1;
+  const LevelSolver* ls; const Operator* op = level_op(h, level, &ls);
+  if (!op || !ls || sd < 0 || sd >= (int)ls->hiermap().sd.size()) return -2;
+  const Subdomain& S = ls->hiermap().sd[sd];
+  *n = (int32_t)S.interior.size();
+  if (nodes) std::copy(S.interior.begin(), S.interior.end(), nodes);
+  return 0;
+}
+int hymls_mi_get_separator_groups(const hymls_mi_t* h, int level, int sd, int32_t* ng, int32_t* gptr, int32_t* gtype,
+                                  int32_t* owned, int32_t* nodes) {
+  if (!h || !h->top) return -1;
+  const LevelSolver* ls; const Operator* op = level_op(h, level, &ls);
+  if (!op || !ls || sd < 0 || sd >= (int)ls->hiermap().sd.size()) return -2;
+  const Subdomain& S = ls->hiermap().sd[sd];
+  *ng = (int32_t)S.groups.size();
+  if (gptr) {
+    int32_t off = 0;
+    for (size_t g = 0; g < S.groups.size(); g++) {
+      gptr[g] = off;
+      if (gtype) gtype[g] = S.groups[g].type;
+      if (owned) owned[g] = std::find(S.owned.begin(), S.owned.end(), (int32_t)g) != S.owned.end();
+      if (nodes) std::copy(S.groups[g].nodes.begin(), S.groups[g].nodes.end(), nodes + off);
+      off += (int32_t)S.groups[g].nodes.size();
+    }
+    gptr[S.groups.size()] = off;
+  }
+  return 0;
+}
+
+int hymls_mi_generate_matrix(int equations, int nx, int ny, int nz, double a, double b, int64_t* nrows, int64_t* nnz,
+                             int32_t* rowptr, int32_t* colind, double* val) {
+  if (!nrows || !nnz) return -2;
+  if (equations == 0) {
+    *nrows = (int64_t)nx * ny * nz;
+    *nnz = generate_laplace3d(nx, ny, nz, rowptr, colind, val);
+  } else if (equations == 1) {
+    *nrows = (int64_t)nx * ny * nz * 4;
+    *nnz = generate_stokes3d(nx, ny, nz, a, b, rowptr, colind, val);
+  } else {
+    return -99;
+  }
+  return 0;
+}
+
+int hymls_mi_generate_testvector(int64_t n, const int32_t* rowptr, const int32_t* colind, const double* val, double* tv) {
+  // create_testvector (reference src/HYMLS_MainUtils.cpp:208-258), Laplace / Stokes-C branch
+  for (int64_t i = 0; i < n; i++) {
+    bool is_diag = true;
+    for (int32_t e = rowptr[i]; e < rowptr[i + 1]; e++)
+      if (val[e] != 0.0 && colind[e] != i) { is_diag = false; break; }
+    tv[i] = is_diag ? 0.0 : 1.0;
+  }
+  return 0;
+}
+
+const char* hymls_mi_last_error(const hymls_mi_t* h) { return h ? h->err.c_str() : "null handle"; }
+
+void hymls_mi_destroy(hymls_mi_t* h) {
+  if (!h) return;
+  try {
+    h->top.reset();
+    dev::free(h->d_b); dev::free(h->d_x);
+  } catch (...) {}
+  delete h;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// common.hpp -- shared host-side types of the MI355X HYMLS hot path.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <numeric>
+#include <cmath>
+
+namespace hymls {
+
+// mirrors HYMLS_SMALL_ENTRY (reference src/HYMLS_Macros.hpp:26-30)
+constexpr double SMALL_ENTRY = 1e-14;
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HYMLS_CHECK(cond, code, msg)                                              \
+  do {                                                                            \
+    if (!(cond)) throw ::hymls::Error((code), std::string(msg) + " [" + __FILE__ + \
+                                               ":" + std::to_string(__LINE__) + "]"); \
+  } while (0)
+
+using ivec = std::vector<int32_t>;
+using dvec = std::vector<double>;
+
+// host CSR matrix with an explicit gid per local row/col (square, same map)
+struct Csr {
+  int32_t n = 0;
+  ivec rowptr, col;  // local column indices
+  dvec val;
+  int64_t nnz() const { return (int64_t)col.size(); }
+};
+
+enum VarType : int32_t { VT_LAPLACE = 0, VT_U = 1, VT_V = 2, VT_W = 3, VT_P = 4, VT_INTERIOR = 5 };
+
+// the reference's "Problem"/"Preconditioner" keys (BasePartitioner.cpp:31-252)
+struct Params {
+  int nx = -1, ny = -1, nz = -1, dim = 3, dof = 1;
+  int sx = 4, sy = -1, sz = -1, cx = -1, cy = -1, cz = -1;
+  int rx = -1, ry = -1, rz = -1;
+  int levels = 1;
+  int partitioner = 0;  // 0 Cartesian, 1 Skew Cartesian
+  int retain_pressures = 1;
+  bool link_velocities = true, link_retained = true;
+  std::vector<int32_t> vtype;    // per dof
+  std::vector<int32_t> fix_gid;  // "Fix GID n"
+  Params next_level() const {  // SetNextLevelParameters (BasePartitioner.cpp:321-346)
+    Params q = *this;
+    q.sx = sx * cx; q.sy = sy * cy; q.sz = sz * cz;
+    return q;
+  }
+};
+
+}  // namespace hymls

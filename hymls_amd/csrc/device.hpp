@@ -1,0 +1,112 @@
+// device.hpp -- the device boundary of the host code: memory, stream, and one launcher
+// per kernel.  The product library implements this with HIP (device_hip.hip); the
+// host-logic simulator under tests/hostsim implements the same functions with plain
+// loops so that the index plans can be validated on a machine without a GPU.
+// Nothing in the product links the simulator.
+#pragma once
+#include "common.hpp"
+#include "symbolic.hpp"
+
+namespace hymls {
+namespace dev {
+
+// ---- runtime
+void init(int device);                 // select device, create stream
+void* stream();                        // hipStream_t (nullptr in the simulator)
+void* alloc(size_t bytes);
+void free(void* p);
+void h2d(void* dst, const void* src, size_t bytes);
+void d2h(void* dst, const void* src, size_t bytes);
+void d2d(void* dst, const void* src, size_t bytes);
+void zero(void* dst, size_t bytes);
+void sync();
+size_t mem_free();
+// event timing on the stream (seconds); ids are small integers
+void timer_start(int id);
+double timer_stop(int id);  // synchronises
+
+template <class T>
+T* upload(const std::vector<T>& v) {
+  T* p = (T*)alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (!v.empty()) h2d(p, v.data(), v.size() * sizeof(T));
+  return p;
+}
+
+// ---- device-side plan of one pattern class (POD, arrays live on the device)
+struct FrontD {
+  int32_t c0, w, ri, rs;
+  int32_t parent, idx_off, rel_off, c_off;
+  int32_t ent_begin, ent_end, child_begin, child_end;
+  int64_t f_off, lp_off, q_off;
+};
+
+struct PlanD {
+  int32_t nI, nS, nfronts, nent;   // nent: entries of the extended local CSR
+  const FrontD* fronts;
+  const int32_t* fidx;
+  const int32_t* rel;
+  const int32_t* children;
+  const int32_t* ent_id;
+  const int32_t* ent_pos;
+  const double* ent_w;
+  int32_t s_ent_begin, s_ent_end;
+  int64_t scratch_size, factor_size;
+  int32_t contrib_size;
+};
+
+// a batch of subdomains of one class
+struct BatchD {
+  int32_t nb;
+  const int32_t* src;    // [nb][plan.nent] index into the level matrix values
+  const int32_t* xoff;   // [nb] offset of the subdomain's interior block in the level vector
+  double* factor;        // [nb][factor_size]
+  double* scratch;       // [chunk][scratch_size]   frontal matrices
+  double* sblock;        // [chunk][nS*nS]          separator (Schur) block, col-major
+  double* contrib;       // [nb][contrib_size]      solve scratch
+  int32_t* flag;         // device int: set != 0 on zero / non-finite pivot
+};
+
+// ---- vector kernels
+void gather(int64_t n, const int32_t* idx, const double* src, double* dst);      // dst[i] = src[idx[i]]
+void scatter(int64_t n, const int32_t* idx, const double* src, double* dst);     // dst[idx[i]] = src[i]
+void axpby(int64_t n, double a, const double* x, double b, double* y);           // y = a x + b y
+void scale_copy(int64_t n, double a, const double* x, double* y);                // y = a x
+// y = alpha * A x + beta * y, CSR with 32-bit indices
+void spmv(int32_t nrows, const int32_t* rowptr, const int32_t* col, const double* val,
+          const double* x, double* y, double alpha, double beta);
+// out[e] = sum_{t in [ptr[e],ptr[e+1])} in[idx[t]]   (deterministic pull-assembly)
+void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out);
+// out[B*blen + k] = sum_{t in [ptr[B],ptr[B+1])} in[base[t] + k], k < blen  (whole dense blocks)
+void pull_sum_blocks(int64_t blen, int32_t nblk, const int64_t* ptr, const int64_t* base,
+                     const double* in, double* out);
+
+// ---- multifrontal numeric factorisation, one tree level, fronts [first, first+count) of
+// `list` (front ids), batch members [b0, b0+nbc) mapped to scratch slots 0..nbc-1
+void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count,
+                  int32_t b0, int32_t nbc, const double* kval);
+// separator block: S = weighted A22 entries (call before the tree), per batch member
+void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const double* kval);
+
+// ---- solves with the factor panels; x is the level vector (interior part), in place
+void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x);
+void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x);
+
+// ---- separator-side kernels
+// Householder per owned group on a level separator vector: x <- 2 w (w.x) - x
+// gptr[ng+1] offsets into the separator vector; w = 0 rows mean "x <- -x" (reference quirk)
+void ot_apply(int32_t ng, const int32_t* gptr, const double* w, double* x);
+// two-sided Householder of every group on the dense separator blocks of a chunk:
+// S_b <- H S_b H ; gptr: local group offsets (shared by the class), tv: [nbc][nS] test vector
+void sblock_transform(int32_t nS, int32_t ng, const int32_t* gptr, const double* tv,
+                      double* sblock, int32_t nbc);
+// out[b][k] = sblock[b][pick[k]]  (extraction of the kept entries)
+void sblock_extract(int32_t nS, int64_t npick, const int32_t* pick, const double* sblock,
+                    double* out, int64_t out_stride, int32_t nbc);
+// batched dense inverse with partial pivoting: nblk blocks of order nb (col-major), in place
+void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag);
+// y[ids] = Binv x[ids] for nblk blocks of order nb; ids: [nblk][nb]
+void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* ids,
+                  const double* x, double* y);
+
+}  // namespace dev
+}  // namespace hymls

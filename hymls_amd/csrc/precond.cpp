@@ -1,0 +1,709 @@
+// precond.cpp -- see precond.hpp
+#include "precond.hpp"
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+namespace hymls {
+
+namespace {
+
+struct Hasher {
+  uint64_t h = 1469598103934665603ULL;
+  void add(const void* p, size_t n) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ULL; }
+  }
+  template <class T> void addv(const std::vector<T>& v) { size_t n = v.size(); add(&n, sizeof n); if (n) add(v.data(), n * sizeof(T)); }
+};
+
+inline void gid_coord(const Params& p, int32_t gid, int32_t* c) {
+  const int var = gid % p.dof, cell = gid / p.dof;
+  const int i = cell % p.nx, j = (cell / p.nx) % p.ny, k = cell / (p.nx * p.ny);
+  const int32_t vt = p.vtype[var];
+  c[0] = 2 * i + (vt == VT_U); c[1] = 2 * j + (vt == VT_V); c[2] = 2 * k + (vt == VT_W);
+}
+
+constexpr int LEAF_SIZE = 24;
+constexpr int MAX_WIDTH = 256;
+constexpr int64_t SCRATCH_BUDGET = 1LL << 30;  // doubles (8 GiB) of frontal scratch per pass
+
+}  // namespace
+
+// ------------------------------------------------------------------ DropByValue
+Csr drop_by_value(const Csr& A, double tol, int kind) {
+  const bool zero_diag = kind == 1, full_diag = kind == 2;
+  Csr R;
+  R.n = A.n;
+  R.rowptr.assign(A.n + 1, 0);
+  dvec diag(A.n, 0.0);
+  std::vector<char> has_diag(A.n, 0);
+  for (int i = 0; i < A.n; i++)
+    for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++)
+      if (A.col[e] == i) { diag[i] = A.val[e]; has_diag[i] = 1; }
+  for (int i = 0; i < A.n; i++) {
+    if (full_diag) { R.col.push_back(i); R.val.push_back(std::abs(diag[i]) > tol ? diag[i] : 0.0); }
+    for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++) {
+      const int j = A.col[e];
+      const bool isd = j == i;
+      if (isd && full_diag) continue;
+      const double scal = isd ? 1.0 : std::max(std::abs(diag[i]), std::abs(diag[j]));
+      const double v = A.val[e];
+      if (std::abs(v) > scal * tol && std::abs(v) > tol) { R.col.push_back(j); R.val.push_back(v); }
+      else if (isd && zero_diag) { R.col.push_back(j); R.val.push_back(0.0); }
+    }
+    R.rowptr[i + 1] = (int32_t)R.col.size();
+  }
+  return R;
+}
+
+// ------------------------------------------------------------------ BatchedLU
+BatchedLU::~BatchedLU() {
+  for (void* p : owned) dev::free(p);
+}
+
+void BatchedLU::upload(int64_t budget, bool with_sblock) {
+  const int nb = (int)members.size();
+  nent = (int32_t)plan.ent_id.size();
+  std::vector<dev::FrontD> fd(plan.fronts.size());
+  for (size_t s = 0; s < fd.size(); s++) {
+    const Front& F = plan.fronts[s];
+    fd[s] = dev::FrontD{F.c0, F.w, F.ri, F.rs, F.parent, F.idx_off, F.rel_off, F.c_off,
+                        F.ent_begin, F.ent_end, F.child_begin, F.child_end, F.f_off, F.lp_off, F.q_off};
+  }
+  auto keep = [&](auto* p) { owned.push_back((void*)p); return p; };
+  dplan.nI = plan.nI; dplan.nS = plan.nS; dplan.nfronts = (int32_t)fd.size(); dplan.nent = nent;
+  dplan.fronts = keep(dev::upload(fd));
+  dplan.fidx = keep(dev::upload(plan.fidx));
+  dplan.rel = keep(dev::upload(plan.rel));
+  dplan.children = keep(dev::upload(plan.children));
+  dplan.ent_id = keep(dev::upload(plan.ent_id));
+  dplan.ent_pos = keep(dev::upload(plan.ent_pos));
+  dplan.ent_w = keep(dev::upload(plan.ent_w));
+  dplan.s_ent_begin = plan.s_ent_begin; dplan.s_ent_end = nent;
+  dplan.scratch_size = plan.scratch_size; dplan.factor_size = plan.factor_size;
+  dplan.contrib_size = plan.contrib_size;
+  for (auto& L : plan.levels) d_lists.push_back(keep(dev::upload(L)));
+  const int64_t per = plan.scratch_size + (with_sblock ? (int64_t)plan.nS * plan.nS : 0);
+  chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nb, budget / std::max<int64_t>(per, 1)));
+  batch.nb = nb;
+  batch.src = keep(dev::upload(h_src));
+  batch.xoff = keep(dev::upload(h_xoff));
+  batch.factor = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)nb * plan.factor_size) * sizeof(double)));
+  batch.scratch = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)chunk * plan.scratch_size) * sizeof(double)));
+  batch.sblock = with_sblock
+                     ? (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)chunk * plan.nS * plan.nS) * sizeof(double)))
+                     : nullptr;
+  batch.contrib = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)nb * plan.contrib_size) * sizeof(double)));
+  batch.flag = (int32_t*)keep(dev::alloc(sizeof(int32_t)));
+  dev::zero(batch.flag, sizeof(int32_t));
+}
+
+void BatchedLU::factor_chunk(const double* kval, int32_t b0, int32_t nbc) {
+  if (batch.sblock) dev::sblock_init(dplan, batch, b0, nbc, kval);
+  for (size_t l = 0; l < plan.levels.size(); l++)
+    dev::factor_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), b0, nbc, kval);
+}
+
+void BatchedLU::solve(double* x) const {
+  const int nl = (int)plan.levels.size();
+  for (int l = 0; l < nl; l++) dev::solve_fwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
+  for (int l = nl - 1; l >= 0; l--) dev::solve_bwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
+}
+
+int32_t BatchedLU::check_flag() const {
+  int32_t f = 0;
+  dev::d2h(&f, batch.flag, sizeof f);
+  return f;
+}
+
+// ------------------------------------------------------------------ DirectSolver
+DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids, int64_t ngid,
+                           const Params& cp) {
+  // CoarseSolver::Compute (reference src/HYMLS_CoarseSolver.cpp:131-152)
+  Csr A = drop_by_value(A0, SMALL_ENTRY, 2);
+  n_ = A.n;
+  for (int32_t g : fix_gids) {
+    int lid = -1;
+    for (int i = 0; i < n_; i++) if (gids[i] == g) { lid = i; break; }
+    HYMLS_CHECK(lid >= 0, -2, "fix GID " + std::to_string(g) + " not in matrix row map");
+    // PutDirichlet (reference src/HYMLS_MatrixUtils.cpp:1229-1309)
+    for (int i = 0; i < n_; i++)
+      for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++) {
+        if (i == lid) A.val[e] = (A.col[e] == lid) ? 1.0 : 0.0;
+        else if (A.col[e] == lid) A.val[e] = 0.0;
+      }
+    fix_lids_.push_back(lid);
+  }
+  if (n_ == 0) return;
+  LocalPattern lp;
+  lp.nI = n_; lp.nS = 0;
+  lp.rowptr = A.rowptr; lp.col = A.col;
+  lp.zero_diag.assign(n_, 1);
+  for (int i = 0; i < n_; i++)
+    for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++)
+      if (A.col[e] == i && A.val[e] != 0.0) lp.zero_diag[i] = 0;
+  lp.coord.resize(3 * (size_t)n_);
+  for (int i = 0; i < n_; i++) gid_coord(cp, gids[i], &lp.coord[3 * (size_t)i]);
+  (void)ngid;
+  lu_.reset(new BatchedLU());
+  lu_->plan = analyse_class(lp, LEAF_SIZE, MAX_WIDTH);
+  lu_->members = {0};
+  lu_->h_xoff = {0};
+  // entry e of the extended CSR is entry e of A
+  lu_->h_src.resize(A.col.size());
+  std::iota(lu_->h_src.begin(), lu_->h_src.end(), 0);
+  lu_->upload(SCRATCH_BUDGET, false);
+  d_val_ = dev::upload(A.val);
+  lu_->factor_chunk(d_val_, 0, 1);
+  HYMLS_CHECK(lu_->check_flag() == 0, -4, "coarse factorisation hit a zero or non-finite pivot");
+  d_z_ = (double*)dev::alloc((size_t)n_ * sizeof(double));
+  d_perm_ = dev::upload(lu_->plan.perm);
+  ivec fixpos;
+  for (int lid : fix_lids_)
+    if (lid > 0) fixpos.push_back(lu_->plan.iperm[lid]);  // CoarseSolver.cpp:288-289: lid 0 is not zeroed
+  fix_lids_ = fixpos;
+  d_fix_ = dev::upload(fix_lids_);
+}
+
+DirectSolver::~DirectSolver() {
+  dev::free(d_val_); dev::free(d_z_); dev::free(d_perm_); dev::free(d_fix_);
+}
+
+void DirectSolver::apply_inverse(const double* b, double* x) {
+  if (n_ == 0) return;
+  dev::gather(n_, d_perm_, b, d_z_);
+  if (!fix_lids_.empty()) {
+    // zero the Dirichlet right-hand sides: scatter zeros
+    static thread_local double* zeros = nullptr;
+    if (!zeros) { zeros = (double*)dev::alloc(16 * sizeof(double)); dev::zero(zeros, 16 * sizeof(double)); }
+    dev::scatter((int64_t)fix_lids_.size(), d_fix_, zeros, d_z_);
+  }
+  lu_->solve(d_z_);
+  dev::scatter(n_, d_perm_, d_z_, x);
+}
+
+void DirectSolver::add_stats(ApplyStats& st, bool) const {
+  if (!lu_) return;
+  st.bytes_coarse += 8.0 * lu_->plan.nnz_factor + 8.0 * 4 * n_;
+}
+
+// ------------------------------------------------------------------ LevelSolver
+struct LevelSolver::Cls {
+  BatchedLU lu;
+  LocalPattern pat;
+  ivec lgptr;                 // offsets of every group in the subdomain's separator list
+  std::vector<ivec> llinked;  // linked sets over all groups (indices)
+  ivec key_extra;             // group types etc. for the class key
+  ivec mult;                  // per entry multiplicity (class key)
+  ivec pick;                  // kept entries of the separator block
+  std::vector<int64_t> blk_off;  // per linked set: offset in the extraction record (-1: no rows)
+  ivec blk_len;
+  int64_t ext_size = 0, ext_base = 0;
+  int32_t ngl = 0;
+  int32_t* d_pick = nullptr;
+  int32_t* d_lgptr = nullptr;
+  dvec tvloc;
+  double* d_tvloc = nullptr;
+  ~Cls() { dev::free(d_pick); dev::free(d_lgptr); dev::free(d_tvloc); }
+};
+
+LevelSolver::LevelSolver(const Params& p, int level, Csr K, ivec gids, dvec testvec, int64_t ngid)
+    : p_(p), level_(level), K_(std::move(K)), gids_(std::move(gids)), tv_(std::move(testvec)), ngid_(ngid) {}
+
+LevelSolver::~LevelSolver() {
+  void* ptrs[] = {d_kval_, d_krow_, d_kcol_, d_inperm_, d_z_, d_t1_, d_t2_, d_y2_, d_a12_row_, d_a12_col_,
+                  d_a12_src_, d_a21_row_, d_a21_col_, d_a21_src_, d_a12_val_, d_a21_val_, d_gptr_, d_otw_,
+                  d_vs_, d_red_pull_ptr_, d_red_pull_idx_, d_red_val_, d_ext_, d_vrhs_, d_vsol_, d_yb_, d_flag_};
+  for (void* q : ptrs) dev::free(q);
+  for (auto& b : blocks_) { dev::free(b.d_binv); dev::free(b.d_ids); dev::free(b.d_pull_ptr); dev::free(b.d_pull_base); }
+}
+
+void LevelSolver::initialize() {
+  const int n = K_.n;
+  HYMLS_CHECK((int)gids_.size() == n && (int)tv_.size() == n, -2, "level: inconsistent sizes");
+  g2l_.assign(ngid_, -1);
+  for (int i = 0; i < n; i++) g2l_[gids_[i]] = i;
+  std::vector<char> present;
+  const bool all = (int64_t)n == ngid_;
+  if (!all) { present.assign(ngid_, 0); for (int32_t g : gids_) present[g] = 1; }
+  hm_ = build_hiermap(p_, all ? nullptr : &present);
+  // separator numbering (map2 = owned groups of sd 0, sd 1, ...)
+  pos2_.assign(n, -1);
+  intidx_.assign(n, -1);
+  sep_row_.clear();
+  gptr_.assign(1, 0);
+  for (auto& S : hm_.sd)
+    for (int gi : S.owned) {
+      for (int32_t g : S.groups[gi].nodes) {
+        const int r = g2l_[g];
+        HYMLS_CHECK(r >= 0 && pos2_[r] < 0, -3, "separator node listed twice or missing");
+        pos2_[r] = (int32_t)sep_row_.size();
+        sep_row_.push_back(r);
+      }
+      gptr_.push_back((int32_t)sep_row_.size());
+    }
+  n2_ = (int32_t)sep_row_.size();
+  direct_schur_ = level_ >= p_.levels;
+  build_classes();
+  HYMLS_CHECK(n1_ + n2_ == n, -3, "partition does not cover the map exactly once");
+  // A12 / A21 in internal numbering
+  a12_row_.assign(n1_ + 1, 0); a21_row_.assign(n2_ + 1, 0);
+  a12_col_.clear(); a12_src_.clear(); a21_col_.clear(); a21_src_.clear();
+  for (int t = 0; t < n1_; t++) {
+    const int r = in_perm_[t];
+    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
+      const int c = K_.col[e];
+      if (pos2_[c] >= 0) { a12_col_.push_back(pos2_[c]); a12_src_.push_back(e); }
+    }
+    a12_row_[t + 1] = (int32_t)a12_col_.size();
+  }
+  for (int k = 0; k < n2_; k++) {
+    const int r = sep_row_[k];
+    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
+      const int c = K_.col[e];
+      if (intidx_[c] >= 0) { a21_col_.push_back(intidx_[c]); a21_src_.push_back(e); }
+    }
+    a21_row_[k + 1] = (int32_t)a21_col_.size();
+  }
+  build_schur_setup();
+  // device residents
+  d_krow_ = dev::upload(K_.rowptr); d_kcol_ = dev::upload(K_.col);
+  d_kval_ = (double*)dev::alloc(std::max<size_t>(1, K_.val.size()) * sizeof(double));
+  d_inperm_ = dev::upload(in_perm_);
+  d_z_ = (double*)dev::alloc((size_t)std::max(n, 1) * sizeof(double));
+  d_t1_ = (double*)dev::alloc((size_t)std::max(n1_, 1) * sizeof(double));
+  d_t2_ = (double*)dev::alloc((size_t)std::max(n2_, 1) * sizeof(double));
+  d_y2_ = (double*)dev::alloc((size_t)std::max(n2_, 1) * sizeof(double));
+  d_yb_ = (double*)dev::alloc((size_t)std::max(n2_, 1) * sizeof(double));
+  d_a12_row_ = dev::upload(a12_row_); d_a12_col_ = dev::upload(a12_col_); d_a12_src_ = dev::upload(a12_src_);
+  d_a21_row_ = dev::upload(a21_row_); d_a21_col_ = dev::upload(a21_col_); d_a21_src_ = dev::upload(a21_src_);
+  d_a12_val_ = (double*)dev::alloc(std::max<size_t>(1, a12_col_.size()) * sizeof(double));
+  d_a21_val_ = (double*)dev::alloc(std::max<size_t>(1, a21_col_.size()) * sizeof(double));
+  d_flag_ = (int32_t*)dev::alloc(sizeof(int32_t));
+  initialized_ = true;
+}
+
+void LevelSolver::build_classes() {
+  const int n = K_.n;
+  const int nsd = (int)hm_.sd.size();
+  // subdomains listing each separator node (for the A22 multiplicities)
+  ivec cnt(n2_ + 1, 0);
+  for (auto& S : hm_.sd) for (auto& g : S.groups) for (int32_t x : g.nodes) cnt[pos2_[g2l_[x]] + 1]++;
+  for (int i = 0; i < n2_; i++) cnt[i + 1] += cnt[i];
+  ivec sdl(cnt[n2_]), fill(cnt.begin(), cnt.end() - 1);
+  for (int s = 0; s < nsd; s++)
+    for (auto& g : hm_.sd[s].groups) for (int32_t x : g.nodes) sdl[fill[pos2_[g2l_[x]]]++] = s;
+  auto common = [&](int a, int b) {
+    int c = 0;
+    for (int i = cnt[a]; i < cnt[a + 1]; i++) for (int j = cnt[b]; j < cnt[b + 1]; j++) c += sdl[i] == sdl[j];
+    return c;
+  };
+  sd_xoff_.assign(nsd, 0); sd_cls_.assign(nsd, -1); sd_bidx_.assign(nsd, -1);
+  ivec loc(n, -1);
+  std::unordered_map<uint64_t, std::vector<int>> table;
+  n1_ = 0;
+  in_perm_.assign(n, -1);
+  for (int s = 0; s < nsd; s++) {
+    const Subdomain& S = hm_.sd[s];
+    LocalPattern lp;
+    lp.nI = (int32_t)S.interior.size();
+    lp.nS = S.num_sep();
+    ivec ext_rows;  // level rows of the extended local numbering
+    ext_rows.reserve(lp.nI + lp.nS);
+    for (int32_t g : S.interior) ext_rows.push_back(g2l_[g]);
+    ivec lgptr(1, 0), key_extra;
+    for (auto& g : S.groups) {
+      for (int32_t x : g.nodes) ext_rows.push_back(g2l_[x]);
+      lgptr.push_back((int32_t)ext_rows.size() - lp.nI);
+      key_extra.push_back(g.type);
+    }
+    for (auto& L : S.linked) { key_extra.push_back(-7); key_extra.insert(key_extra.end(), L.begin(), L.end()); }
+    const int ne = lp.nI + lp.nS;
+    for (int i = 0; i < ne; i++) {
+      HYMLS_CHECK(ext_rows[i] >= 0 && loc[ext_rows[i]] < 0, -3, "node listed twice in a subdomain");
+      loc[ext_rows[i]] = i;
+    }
+    lp.rowptr.assign(ne + 1, 0);
+    lp.zero_diag.assign(lp.nI, 1);
+    ivec src, mult;
+    for (int i = 0; i < ne; i++) {
+      const int r = ext_rows[i];
+      for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
+        const int c = K_.col[e], lc = loc[c];
+        if (lc < 0) {
+          HYMLS_CHECK(!(i < lp.nI && pos2_[c] < 0), -2,
+                      "partitioning does not decouple the interiors of different subdomains");
+          continue;
+        }
+        int m = 1;
+        if (i >= lp.nI && lc >= lp.nI) {
+          m = common(pos2_[r], pos2_[c]);
+          HYMLS_CHECK(m > 0, -3, "separator coupling not inside any subdomain");
+        }
+        lp.col.push_back(lc); src.push_back(e); mult.push_back(m);
+        lp.weight.push_back(1.0 / m);
+        if (lc == i && i < lp.nI && K_.val[e] != 0.0) lp.zero_diag[i] = 0;
+      }
+      lp.rowptr[i + 1] = (int32_t)lp.col.size();
+    }
+    for (int i = 0; i < ne; i++) loc[ext_rows[i]] = -1;
+    // relative coordinates
+    lp.coord.resize(3 * (size_t)lp.nI);
+    int32_t mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
+    for (int i = 0; i < lp.nI; i++) {
+      gid_coord(p_, S.interior[i], &lp.coord[3 * (size_t)i]);
+      for (int a = 0; a < 3; a++) mn[a] = std::min(mn[a], lp.coord[3 * (size_t)i + a]);
+    }
+    for (int i = 0; i < lp.nI; i++) for (int a = 0; a < 3; a++) lp.coord[3 * (size_t)i + a] -= mn[a] & ~1;
+    Hasher H;
+    H.add(&lp.nI, 4); H.add(&lp.nS, 4);
+    H.addv(lp.rowptr); H.addv(lp.col); H.addv(lp.zero_diag); H.addv(lp.coord); H.addv(mult);
+    H.addv(lgptr); H.addv(key_extra);
+    int cid = -1;
+    for (int c : table[H.h]) {
+      Cls& C = *cls_[c];
+      if (C.pat.nI == lp.nI && C.pat.nS == lp.nS && C.pat.rowptr == lp.rowptr && C.pat.col == lp.col &&
+          C.pat.zero_diag == lp.zero_diag && C.pat.coord == lp.coord && C.mult == mult && C.lgptr == lgptr &&
+          C.key_extra == key_extra) { cid = c; break; }
+    }
+    if (cid < 0) {
+      cid = (int)cls_.size();
+      cls_.emplace_back(new Cls());
+      Cls& C = *cls_.back();
+      C.lu.plan = analyse_class(lp, LEAF_SIZE, MAX_WIDTH);
+      C.pat = std::move(lp);
+      C.mult = mult; C.lgptr = lgptr; C.key_extra = key_extra;
+      C.llinked = S.linked;
+      C.ngl = (int32_t)S.groups.size();
+      table[H.h].push_back(cid);
+    }
+    Cls& C = *cls_[cid];
+    sd_cls_[s] = cid;
+    sd_bidx_[s] = (int32_t)C.lu.members.size();
+    sd_xoff_[s] = n1_;
+    C.lu.members.push_back(s);
+    C.lu.h_xoff.push_back(n1_);
+    // map the class's entry numbering (plan.ent_id refers to the extended CSR) onto this member
+    C.lu.h_src.insert(C.lu.h_src.end(), src.begin(), src.end());
+    for (int t = 0; t < C.pat.nI; t++) {
+      const int r = g2l_[S.interior[C.lu.plan.perm[t]]];
+      in_perm_[n1_ + t] = r;
+      intidx_[r] = n1_ + t;
+    }
+    n1_ += C.pat.nI;
+  }
+  for (int k = 0; k < n2_; k++) in_perm_[n1_ + k] = sep_row_[k];
+}
+
+void LevelSolver::build_schur_setup() {
+  const int nsd = (int)hm_.sd.size();
+  const int ng_total = (int)gptr_.size() - 1;
+  // ---- per class: what to keep of the (transformed) separator block
+  ext_total_ = 0;
+  for (auto& cp : cls_) {
+    Cls& C = *cp;
+    const int nS = C.pat.nS;
+    C.pick.clear(); C.blk_off.clear(); C.blk_len.clear();
+    if (direct_schur_) {
+      C.pick.resize((size_t)nS * nS);
+      std::iota(C.pick.begin(), C.pick.end(), 0);
+    } else {
+      for (int b = 0; b < C.ngl; b++) for (int a = 0; a < C.ngl; a++) C.pick.push_back(C.lgptr[a] + nS * C.lgptr[b]);
+      for (auto& L : C.llinked) {
+        ivec locs;
+        for (int gi : L) for (int t = C.lgptr[gi] + 1; t < C.lgptr[gi + 1]; t++) locs.push_back(t);
+        C.blk_len.push_back((int32_t)locs.size());
+        C.blk_off.push_back(locs.empty() ? -1 : (int64_t)C.pick.size());
+        for (int b : locs) for (int a : locs) C.pick.push_back(a + nS * b);
+      }
+    }
+    C.ext_size = (int64_t)C.pick.size();
+    C.ext_base = ext_total_;
+    ext_total_ += C.ext_size * (int64_t)C.lu.members.size();
+    // test vector at the separators of every member
+    C.tvloc.assign((size_t)nS * C.lu.members.size(), 1.0);
+    for (size_t b = 0; b < C.lu.members.size(); b++) {
+      const Subdomain& S = hm_.sd[C.lu.members[b]];
+      size_t t = 0;
+      for (auto& g : S.groups) for (int32_t x : g.nodes) C.tvloc[b * nS + t++] = tv_[g2l_[x]];
+    }
+  }
+  // ---- pull lists
+  std::vector<std::pair<int64_t, int64_t>> coo;
+  if (direct_schur_) {
+    red_.n = n2_;
+    for (int s = 0; s < nsd; s++) {
+      const Subdomain& S = hm_.sd[s];
+      const Cls& C = *cls_[sd_cls_[s]];
+      const int nS = C.pat.nS;
+      ivec gp;
+      for (auto& g : S.groups) for (int32_t x : g.nodes) gp.push_back(pos2_[g2l_[x]]);
+      const int64_t base = C.ext_base + (int64_t)sd_bidx_[s] * C.ext_size;
+      for (int b = 0; b < nS; b++)
+        for (int a = 0; a < nS; a++) coo.emplace_back((int64_t)gp[a] * n2_ + gp[b], base + a + (int64_t)nS * b);
+    }
+  } else {
+    // Householder rows (InitializeOT, reference src/HYMLS_SchurPreconditioner.cpp:384-467 +
+    // Householder::Construct, src/HYMLS_Householder.cpp:128-163)
+    otw_.assign(n2_, 0.0);
+    vs_.resize(ng_total);
+    for (int g = 0; g < ng_total; g++) {
+      const int b = gptr_[g], e = gptr_[g + 1];
+      vs_[g] = b;
+      dvec v(e - b);
+      for (int i = b; i < e; i++) v[i - b] = tv_[sep_row_[i]];
+      const double sg = v[0] < 0 ? -1.0 : (v[0] > 0 ? 1.0 : 0.0);
+      double nrm = 0;
+      for (double& x : v) { x *= sg; nrm += x * x; }
+      nrm = std::sqrt(nrm);
+      v[0] += nrm;
+      double nrm2 = 0;
+      for (double x : v) nrm2 += x * x;
+      nrm2 = std::sqrt(nrm2);
+      if (nrm2 < SMALL_ENTRY) continue;  // no row in T: the transform acts as -I (reference quirk)
+      for (int i = b; i < e; i++) otw_[i] = v[i - b] / nrm2;
+    }
+    // owned group lookup by first gid
+    std::unordered_map<int32_t, int32_t> gidx_of_first;
+    {
+      int g = 0;
+      for (auto& S : hm_.sd) for (int gi : S.owned) gidx_of_first[S.groups[gi].nodes[0]] = g++;
+    }
+    // dense blocks: one per owned linked set with at least one non-V-sum row
+    std::map<int32_t, int> bc_of_size;
+    std::unordered_map<int32_t, std::pair<int, int>> block_of_key;  // first group's vsum gid -> (class, index)
+    for (int s = 0; s < nsd; s++) {
+      const Subdomain& S = hm_.sd[s];
+      for (auto& L : S.owned_linked) {
+        ivec ids;
+        for (int gi : L) for (size_t t = 1; t < S.groups[gi].nodes.size(); t++) ids.push_back(pos2_[g2l_[S.groups[gi].nodes[t]]]);
+        if (ids.empty()) continue;
+        const int nb = (int)ids.size();
+        if (!bc_of_size.count(nb)) { bc_of_size[nb] = (int)blocks_.size(); blocks_.emplace_back(); blocks_.back().nb = nb; }
+        BlockClass& B = blocks_[bc_of_size[nb]];
+        block_of_key[S.groups[L[0]].nodes[0]] = {bc_of_size[nb], B.nblk};
+        B.ids.insert(B.ids.end(), ids.begin(), ids.end());
+        B.nblk++;
+      }
+    }
+    std::vector<std::vector<std::vector<int64_t>>> contrib(blocks_.size());
+    for (size_t c = 0; c < blocks_.size(); c++) contrib[c].resize(blocks_[c].nblk);
+    red_.n = ng_total;
+    for (int s = 0; s < nsd; s++) {
+      const Subdomain& S = hm_.sd[s];
+      const Cls& C = *cls_[sd_cls_[s]];
+      const int64_t base = C.ext_base + (int64_t)sd_bidx_[s] * C.ext_size;
+      ivec vg(C.ngl);
+      for (int a = 0; a < C.ngl; a++) {
+        auto it = gidx_of_first.find(S.groups[a].nodes[0]);
+        HYMLS_CHECK(it != gidx_of_first.end(), -3, "separator group without owner");
+        vg[a] = it->second;
+        HYMLS_CHECK(gptr_[vg[a] + 1] - gptr_[vg[a]] == (int)S.groups[a].nodes.size(), -3, "group differs between subdomains");
+      }
+      for (int b = 0; b < C.ngl; b++)
+        for (int a = 0; a < C.ngl; a++) coo.emplace_back((int64_t)vg[a] * ng_total + vg[b], base + a + (int64_t)C.ngl * b);
+      for (size_t li = 0; li < S.linked.size(); li++) {
+        if (C.blk_off[li] < 0) continue;
+        auto it = block_of_key.find(S.groups[S.linked[li][0]].nodes[0]);
+        HYMLS_CHECK(it != block_of_key.end(), -3, "linked separator set without owner");
+        BlockClass& B = blocks_[it->second.first];
+        HYMLS_CHECK(B.nb == C.blk_len[li], -3, "linked separator set differs between subdomains");
+        // same node order as the owner's block?
+        size_t t = 0;
+        for (int gi : S.linked[li])
+          for (size_t q = 1; q < S.groups[gi].nodes.size(); q++, t++)
+            HYMLS_CHECK(B.ids[(size_t)it->second.second * B.nb + t] == pos2_[g2l_[S.groups[gi].nodes[q]]], -3,
+                        "linked separator set ordered differently between subdomains");
+        contrib[it->second.first][it->second.second].push_back(base + C.blk_off[li]);
+      }
+    }
+    for (size_t c = 0; c < blocks_.size(); c++) {
+      BlockClass& B = blocks_[c];
+      B.pull_ptr.assign(1, 0);
+      for (auto& v : contrib[c]) { B.pull_base.insert(B.pull_base.end(), v.begin(), v.end()); B.pull_ptr.push_back((int64_t)B.pull_base.size()); }
+      B.d_ids = dev::upload(B.ids);
+      B.d_pull_ptr = dev::upload(B.pull_ptr); B.d_pull_base = dev::upload(B.pull_base);
+      B.d_binv = (double*)dev::alloc((size_t)B.nb * B.nb * B.nblk * sizeof(double));
+    }
+    d_gptr_ = dev::upload(gptr_); d_otw_ = dev::upload(otw_); d_vs_ = dev::upload(vs_);
+    d_vrhs_ = (double*)dev::alloc((size_t)std::max(ng_total, 1) * sizeof(double));
+    d_vsol_ = (double*)dev::alloc((size_t)std::max(ng_total, 1) * sizeof(double));
+  }
+  // COO -> CSR pattern with pull lists
+  std::sort(coo.begin(), coo.end());
+  const int64_t nr = red_.n;
+  red_.rowptr.assign(nr + 1, 0); red_.col.clear();
+  red_pull_ptr_.assign(1, 0); red_pull_idx_.clear();
+  red_pull_idx_.reserve(coo.size());
+  for (size_t k = 0; k < coo.size();) {
+    size_t k2 = k;
+    while (k2 < coo.size() && coo[k2].first == coo[k].first) { red_pull_idx_.push_back(coo[k2].second); k2++; }
+    const int64_t r = coo[k].first / nr, c = coo[k].first % nr;
+    red_.col.push_back((int32_t)c);
+    red_.rowptr[r + 1]++;
+    red_pull_ptr_.push_back((int64_t)red_pull_idx_.size());
+    k = k2;
+  }
+  for (int64_t r = 0; r < nr; r++) red_.rowptr[r + 1] += red_.rowptr[r];
+  red_.val.assign(red_.col.size(), 0.0);
+  d_red_pull_ptr_ = dev::upload(red_pull_ptr_); d_red_pull_idx_ = dev::upload(red_pull_idx_);
+  d_red_val_ = (double*)dev::alloc(std::max<size_t>(1, red_.col.size()) * sizeof(double));
+  d_ext_ = (double*)dev::alloc(std::max<int64_t>(1, ext_total_) * sizeof(double));
+  for (auto& cp : cls_) {
+    Cls& C = *cp;
+    C.d_pick = dev::upload(C.pick);
+    C.d_lgptr = dev::upload(C.lgptr);
+    C.d_tvloc = dev::upload(C.tvloc);
+    C.lu.upload(SCRATCH_BUDGET, true);
+  }
+}
+
+void LevelSolver::set_values(const dvec& val) {
+  HYMLS_CHECK(val.size() == K_.val.size(), -2, "SetMatrix: pattern changed");
+  K_.val = val;
+}
+
+void LevelSolver::compute() {
+  HYMLS_CHECK(initialized_, -1, "level not initialized");
+  dev::h2d(d_kval_, K_.val.data(), K_.val.size() * sizeof(double));
+  dev::gather((int64_t)a12_col_.size(), d_a12_src_, d_kval_, d_a12_val_);
+  dev::gather((int64_t)a21_col_.size(), d_a21_src_, d_kval_, d_a21_val_);
+  // ---- interior factorisations + separator blocks, class by class, chunk by chunk
+  for (auto& cp : cls_) {
+    Cls& C = *cp;
+    dev::zero(C.lu.batch.flag, sizeof(int32_t));
+    const int nb = (int)C.lu.members.size();
+    for (int b0 = 0; b0 < nb; b0 += C.lu.chunk) {
+      const int nbc = std::min(C.lu.chunk, nb - b0);
+      C.lu.factor_chunk(d_kval_, b0, nbc);
+      if (C.pat.nS == 0) continue;
+      if (!direct_schur_)
+        dev::sblock_transform(C.pat.nS, C.ngl, C.d_lgptr, C.d_tvloc + (size_t)b0 * C.pat.nS, C.lu.batch.sblock, nbc);
+      dev::sblock_extract(C.pat.nS, C.ext_size, C.d_pick, C.lu.batch.sblock,
+                          d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size, C.ext_size, nbc);
+    }
+    HYMLS_CHECK(C.lu.check_flag() == 0, -4, "subdomain factorisation hit a zero or non-finite pivot (level " +
+                                                std::to_string(level_) + ")");
+  }
+  // ---- assemble what is kept of the Schur complement
+  dev::pull_sum((int64_t)red_.col.size(), d_red_pull_ptr_, d_red_pull_idx_, d_ext_, d_red_val_);
+  dev::d2h(red_.val.data(), d_red_val_, red_.val.size() * sizeof(double));
+  ivec next_gids;
+  if (direct_schur_) {
+    // Preconditioner.cpp:485-500: S assembled, DropByValue (RelZeroDiag), CoarseSolver
+    for (int k = 0; k < n2_; k++) next_gids.push_back(gids_[sep_row_[k]]);
+    Csr S = drop_by_value(red_, SMALL_ENTRY, 1);
+    next_.reset();
+    next_level_ = nullptr;
+    next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_));
+    return;
+  }
+  dev::zero(d_flag_, sizeof(int32_t));
+  for (auto& B : blocks_) {
+    // block values = sum of the contributions of every adjacent subdomain, then LU + inverse
+    // (Ifpack_DenseContainer::Compute -> dgetrf in the reference, SchurPreconditioner.cpp:284-291)
+    const int64_t bl = (int64_t)B.nb * B.nb;
+    dev::pull_sum_blocks(bl, B.nblk, B.d_pull_ptr, B.d_pull_base, d_ext_, B.d_binv);
+    dev::dense_invert(B.nb, B.nblk, B.d_binv, d_flag_);
+  }
+  int32_t flag = 0;
+  dev::d2h(&flag, d_flag_, sizeof flag);
+  HYMLS_CHECK(flag == 0, -4,
+              "singular separator block on level " + std::to_string(level_) +
+                  " (3D Stokes-C needs the Skew Cartesian partitioner: isolated pressure 'tubes' on subdomain edges)");
+  // ---- next level (ComputeNextLevel, reference src/HYMLS_SchurPreconditioner.cpp:520-629)
+  Csr R = drop_by_value(red_, SMALL_ENTRY, 0);
+  const int ng = (int)vs_.size();
+  next_gids.resize(ng);
+  for (int g = 0; g < ng; g++) next_gids[g] = gids_[sep_row_[vs_[g]]];
+  if (level_ + 1 < p_.levels) {
+    if (next_level_ && next_pattern_key_rowptr_ == R.rowptr && next_pattern_key_col_ == R.col) {
+      next_level_->set_values(R.val);
+    } else {
+      // next test vector = V-sum part of H * testvector (:569-573)
+      dvec tvn(ng);
+      for (int g = 0; g < ng; g++) {
+        double dot = 0;
+        for (int i = gptr_[g]; i < gptr_[g + 1]; i++) dot += otw_[i] * tv_[sep_row_[i]];
+        tvn[g] = 2.0 * otw_[gptr_[g]] * dot - tv_[sep_row_[gptr_[g]]];
+      }
+      next_pattern_key_rowptr_ = R.rowptr; next_pattern_key_col_ = R.col;
+      next_level_ = new LevelSolver(p_.next_level(), level_ + 1, R, next_gids, tvn, ngid_);
+      next_.reset(next_level_);
+      next_level_->initialize();
+    }
+    next_level_->profiling = profiling;
+    next_level_->compute();
+  } else {
+    next_level_ = nullptr;
+    next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_));
+  }
+}
+
+void LevelSolver::interior_solve(double* x1) {
+  for (auto& cp : cls_) cp->lu.solve(x1);
+}
+
+void LevelSolver::schur_apply(double* rhs2, double* x2) {
+  if (n2_ == 0) return;
+  if (direct_schur_) { next_->apply_inverse(rhs2, x2); return; }
+  // SchurPreconditioner::ApplyInverse (reference src/HYMLS_SchurPreconditioner.cpp:1010-1093)
+  const int ng = (int)vs_.size();
+  dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);                       // B' = H rhs
+  for (auto& B : blocks_) dev::blocks_apply(B.nb, B.nblk, B.d_binv, B.d_ids, rhs2, x2);
+  dev::gather(ng, d_vs_, rhs2, d_vrhs_);
+  next_->apply_inverse(d_vrhs_, d_vsol_);
+  dev::scatter(ng, d_vs_, d_vsol_, x2);
+  dev::ot_apply(ng, d_gptr_, d_otw_, x2);                         // Y = H Y
+}
+
+void LevelSolver::apply_inverse(const double* b, double* x) {
+  HYMLS_CHECK(next_ != nullptr || n2_ == 0, -1, "The preconditioner has not yet been computed.");
+  // Preconditioner::ApplyInverse (reference src/HYMLS_Preconditioner.cpp:930-1070)
+  const int n = K_.n;
+  double* z1 = d_z_;
+  double* z2 = d_z_ + n1_;
+  if (profiling) dev::timer_start(0);
+  dev::gather(n, d_inperm_, b, d_z_);                       // b1, b2
+  if (profiling) dev::timer_start(1);
+  interior_solve(z1);                                       // x1 = A11 \ b1
+  if (profiling) phase_seconds[1] = dev::timer_stop(1);
+  if (profiling) dev::timer_start(2);
+  dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1, z2, -1.0, 1.0);  // b2 - A21 x1
+  if (profiling) phase_seconds[2] = dev::timer_stop(2);
+  if (profiling) dev::timer_start(3);
+  schur_apply(z2, d_t2_);                                   // x2
+  if (profiling) phase_seconds[3] = dev::timer_stop(3);
+  if (profiling) dev::timer_start(2);
+  dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0);  // y1 = A12 x2
+  if (profiling) phase_seconds[2] += dev::timer_stop(2);
+  if (profiling) dev::timer_start(1);
+  interior_solve(d_t1_);                                    // A11 \ y1
+  if (profiling) phase_seconds[1] += dev::timer_stop(1);
+  dev::axpby(n1_, -1.0, d_t1_, 1.0, z1);                    // x1 -= ...
+  dev::d2d(z2, d_t2_, (size_t)n2_ * sizeof(double));
+  dev::scatter(n, d_inperm_, d_z_, x);
+  if (profiling) phase_seconds[0] = dev::timer_stop(0);
+}
+
+void LevelSolver::matvec(const double* x, double* y) const {
+  dev::spmv(K_.n, d_krow_, d_kcol_, d_kval_, x, y, 1.0, 0.0);
+}
+
+void LevelSolver::add_stats(ApplyStats& st, bool as_coarse) const {
+  double f = 0, sp = 0, sep = 0, vec = 0;
+  for (auto& cp : cls_) f += 2.0 * 8.0 * (double)cp->lu.plan.nnz_factor * (double)cp->lu.members.size();
+  sp = 12.0 * (double)(a12_col_.size() + a21_col_.size()) + 4.0 * (n1_ + n2_ + 2);
+  if (!direct_schur_) {
+    sep = 2.0 * 12.0 * n2_;
+    for (auto& B : blocks_) sep += (8.0 * B.nb * B.nb + 4.0 * B.nb) * B.nblk;
+  }
+  const double N = (double)K_.n;
+  vec = 8.0 * (4.0 * N + 7.0 * n1_ + 12.0 * n2_);
+  if (as_coarse) st.bytes_coarse += f + sp + sep + vec;
+  else { st.bytes_factor += f; st.bytes_spmv += sp; st.bytes_sep += sep; st.bytes_vec += vec; }
+  if (next_) next_->add_stats(st, true);
+}
+
+}  // namespace hymls

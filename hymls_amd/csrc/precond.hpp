@@ -1,0 +1,149 @@
+// precond.hpp -- host orchestration of the multilevel preconditioner on one GPU.
+//
+// LevelSolver is one HYMLS::Preconditioner level (reference src/HYMLS_Preconditioner.cpp)
+// together with its SchurPreconditioner (src/HYMLS_SchurPreconditioner.cpp); DirectSolver is
+// the CoarseSolver (src/HYMLS_CoarseSolver.cpp) and also the engine behind every batched
+// interior solve.  All integer work happens here on the host, once; all floating point
+// work of Compute/ApplyInverse runs in the kernels behind device.hpp.
+#pragma once
+#include <memory>
+#include "common.hpp"
+#include "partition.hpp"
+#include "symbolic.hpp"
+#include "device.hpp"
+
+namespace hymls {
+
+struct ApplyStats {
+  double bytes_factor = 0, bytes_spmv = 0, bytes_sep = 0, bytes_coarse = 0, bytes_vec = 0;
+};
+
+// batched multifrontal LU of one pattern class, resident on the device
+struct BatchedLU {
+  ClassPlan plan;
+  ivec members;                 // caller-defined ids (level subdomain ids)
+  ivec h_xoff;
+  ivec h_src;                   // [nb][nent]
+  // device
+  dev::PlanD dplan{};
+  dev::BatchD batch{};
+  std::vector<int32_t*> d_lists;  // per tree level
+  std::vector<void*> owned;       // device allocations to free
+  int32_t nent = 0;
+  int32_t chunk = 0;              // members factored per pass
+  ~BatchedLU();
+  void upload(int64_t scratch_budget_doubles, bool with_sblock);
+  // numeric factorisation of members [b0,b0+nbc) (scratch slots 0..nbc-1)
+  void factor_chunk(const double* kval, int32_t b0, int32_t nbc);
+  void solve(double* x) const;    // forward + backward, all members, in place
+  int32_t check_flag() const;
+};
+
+class Operator {  // something with ApplyInverse on device vectors in its own row ordering
+ public:
+  virtual ~Operator() {}
+  virtual void apply_inverse(const double* b, double* x) = 0;
+  virtual int64_t size() const = 0;
+  virtual void add_stats(ApplyStats& st, bool as_coarse) const = 0;
+};
+
+// CoarseSolver: exact sparse LU of one matrix (after dropping / Dirichlet fixes)
+class DirectSolver : public Operator {
+ public:
+  DirectSolver(const Csr& A, const ivec& gids, const ivec& fix_gids, int64_t ngid, const Params& coord_params);
+  ~DirectSolver() override;
+  void apply_inverse(const double* b, double* x) override;
+  int64_t size() const override { return n_; }
+  void add_stats(ApplyStats& st, bool as_coarse) const override;
+
+ private:
+  int32_t n_ = 0;
+  std::unique_ptr<BatchedLU> lu_;
+  double* d_val_ = nullptr;
+  double* d_z_ = nullptr;
+  int32_t* d_perm_ = nullptr;   // elimination position -> row
+  ivec fix_lids_;
+  int32_t* d_fix_ = nullptr;
+};
+
+class LevelSolver : public Operator {
+ public:
+  LevelSolver(const Params& p, int level, Csr K, ivec gids, dvec testvec, int64_t ngid);
+  ~LevelSolver() override;
+  void initialize();
+  void compute();                       // uses the host values of K (uploads them)
+  void set_values(const dvec& val);     // SetMatrix with unchanged pattern
+  void apply_inverse(const double* b, double* x) override;
+  int64_t size() const override { return K_.n; }
+  void add_stats(ApplyStats& st, bool as_coarse) const override;
+  void matvec(const double* x, double* y) const;  // y = K x (level ordering)
+
+  // introspection
+  const HierMap& hiermap() const { return hm_; }
+  int level() const { return level_; }
+  int64_t schur_size() const { return n2_; }
+  Operator* next() const { return next_.get(); }
+  LevelSolver* next_level() const { return next_level_; }
+  double phase_seconds[5] = {0, 0, 0, 0, 0};
+  bool profiling = false;
+
+ private:
+  struct Cls;
+  void build_classes();
+  void build_schur_setup();
+  void schur_apply(double* rhs2, double* x2);
+  void interior_solve(double* x1);
+
+  Params p_;
+  int level_;
+  Csr K_;
+  ivec gids_;
+  dvec tv_;
+  int64_t ngid_;
+  HierMap hm_;
+  int32_t n1_ = 0, n2_ = 0;
+  ivec g2l_;                 // gid -> level row (-1)
+  ivec sep_row_;             // separator index -> level row
+  ivec pos2_;                // level row -> separator index (-1)
+  ivec intidx_;              // level row -> internal interior index (-1)
+  ivec in_perm_;             // internal index -> level row
+  ivec sd_xoff_, sd_cls_, sd_bidx_;
+  std::vector<std::unique_ptr<Cls>> cls_;
+  // device
+  double* d_kval_ = nullptr;
+  int32_t *d_krow_ = nullptr, *d_kcol_ = nullptr;
+  int32_t* d_inperm_ = nullptr;
+  double *d_z_ = nullptr, *d_t1_ = nullptr, *d_t2_ = nullptr, *d_y2_ = nullptr;
+  // A12 / A21
+  ivec a12_row_, a12_col_, a12_src_, a21_row_, a21_col_, a21_src_;
+  int32_t *d_a12_row_ = nullptr, *d_a12_col_ = nullptr, *d_a12_src_ = nullptr;
+  int32_t *d_a21_row_ = nullptr, *d_a21_col_ = nullptr, *d_a21_src_ = nullptr;
+  double *d_a12_val_ = nullptr, *d_a21_val_ = nullptr;
+  // Schur preconditioner data
+  bool direct_schur_ = false;
+  ivec gptr_;                // owned groups: offsets into the separator vector
+  dvec otw_;                 // Householder rows (n2)
+  ivec vs_;                  // V-sum separator indices (one per owned group)
+  int32_t* d_gptr_ = nullptr; double* d_otw_ = nullptr; int32_t* d_vs_ = nullptr;
+  struct BlockClass { int32_t nb = 0, nblk = 0; ivec ids; ivec owner_key; double* d_binv = nullptr; int32_t* d_ids = nullptr;
+                      std::vector<int64_t> pull_ptr, pull_base; int64_t* d_pull_ptr = nullptr; int64_t* d_pull_base = nullptr; };
+  std::vector<BlockClass> blocks_;
+  // reduced (V-sum) matrix or full Schur complement: pattern + pull lists
+  Csr red_;                  // pattern (host), values filled after compute
+  std::vector<int64_t> red_pull_ptr_, red_pull_idx_;
+  int64_t *d_red_pull_ptr_ = nullptr, *d_red_pull_idx_ = nullptr;
+  double* d_red_val_ = nullptr;
+  double* d_ext_ = nullptr; int64_t ext_total_ = 0;
+  double *d_vrhs_ = nullptr, *d_vsol_ = nullptr, *d_yb_ = nullptr;
+  int32_t* d_flag_ = nullptr;
+  std::unique_ptr<Operator> next_;
+  LevelSolver* next_level_ = nullptr;
+  ivec next_pattern_key_rowptr_, next_pattern_key_col_;
+  bool initialized_ = false;
+};
+
+// MatrixUtils::DropByValue (reference src/HYMLS_MatrixUtils.cpp:1011-1212); kind:
+// 0 RelDropDiag, 1 RelZeroDiag, 2 RelFullDiag
+Csr drop_by_value(const Csr& A, double tol, int kind);
+
+}  // namespace hymls

@@ -1,0 +1,289 @@
+// symbolic.cpp -- see symbolic.hpp
+#include "symbolic.hpp"
+
+namespace hymls {
+
+namespace {
+
+struct NdCtx {
+  const std::vector<ivec>* vadj;  // V-graph adjacency (local interior ids)
+  const ivec* coord;
+  int leaf;
+  std::vector<char> side;                  // scratch marks
+  std::vector<std::pair<int, int>> snodes; // (begin, end) into order
+  ivec order;                              // V nodes in elimination order
+};
+
+void nd_recurse(NdCtx& c, ivec& nodes) {
+  const int n = (int)nodes.size();
+  if (n == 0) return;
+  auto emit_leaf = [&](ivec& v) {
+    const ivec& co = *c.coord;
+    std::sort(v.begin(), v.end(), [&](int a, int b) {
+      if (co[3 * a + 2] != co[3 * b + 2]) return co[3 * a + 2] < co[3 * b + 2];
+      if (co[3 * a + 1] != co[3 * b + 1]) return co[3 * a + 1] < co[3 * b + 1];
+      if (co[3 * a] != co[3 * b]) return co[3 * a] < co[3 * b];
+      return a < b;
+    });
+    const int b = (int)c.order.size();
+    c.order.insert(c.order.end(), v.begin(), v.end());
+    c.snodes.emplace_back(b, (int)c.order.size());
+  };
+  if (n <= c.leaf) { emit_leaf(nodes); return; }
+  const ivec& co = *c.coord;
+  int lo[3], hi[3];
+  for (int a = 0; a < 3; a++) { lo[a] = INT32_MAX; hi[a] = INT32_MIN; }
+  for (int v : nodes)
+    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], co[3 * v + a]); hi[a] = std::max(hi[a], co[3 * v + a]); }
+  int axes[3] = {0, 1, 2};
+  std::sort(axes, axes + 3, [&](int a, int b) { return (hi[a] - lo[a]) > (hi[b] - lo[b]); });
+  for (int t = 0; t < 3; t++) {
+    const int ax = axes[t];
+    if (hi[ax] == lo[ax]) break;
+    // split value: the coordinate whose "< value" set is closest to half
+    ivec cs(n);
+    for (int i = 0; i < n; i++) cs[i] = co[3 * nodes[i] + ax];
+    std::sort(cs.begin(), cs.end());
+    int best = -1, bestd = n + 1;
+    for (int i = 1; i < n; i++)
+      if (cs[i] != cs[i - 1]) {  // i = count of coords < cs[i]
+        const int d = std::abs(i - n / 2);
+        if (d < bestd) { bestd = d; best = cs[i]; }
+      }
+    if (best == -1) continue;
+    ivec L, R;
+    for (int v : nodes) {
+      if (co[3 * v + ax] < best) { L.push_back(v); c.side[v] = 1; }
+      else { R.push_back(v); c.side[v] = 2; }
+    }
+    ivec sepR, sepL;
+    for (int v : R)
+      for (int u : (*c.vadj)[v]) if (c.side[u] == 1) { sepR.push_back(v); break; }
+    for (int v : L)
+      for (int u : (*c.vadj)[v]) if (c.side[u] == 2) { sepL.push_back(v); break; }
+    const bool useR = sepR.size() <= sepL.size();
+    ivec& sep = useR ? sepR : sepL;
+    for (int v : sep) c.side[v] = 3;
+    ivec L2, R2;
+    for (int v : L) if (c.side[v] == 1) L2.push_back(v);
+    for (int v : R) if (c.side[v] == 2) R2.push_back(v);
+    for (int v : nodes) c.side[v] = 0;
+    if (L2.empty() && R2.empty()) { emit_leaf(nodes); return; }
+    nd_recurse(c, L2);
+    nd_recurse(c, R2);
+    if (!sep.empty()) emit_leaf(sep);
+    return;
+  }
+  emit_leaf(nodes);
+}
+
+}  // namespace
+
+ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width) {
+  ClassPlan P;
+  const int nI = lp.nI, nS = lp.nS, n = nI + nS;
+  P.nI = nI; P.nS = nS;
+  // --- symmetric adjacency of the extended pattern
+  std::vector<ivec> adj(n);
+  for (int i = 0; i < n; i++)
+    for (int e = lp.rowptr[i]; e < lp.rowptr[i + 1]; e++) {
+      const int j = lp.col[e];
+      if (j != i) { adj[i].push_back(j); adj[j].push_back(i); }
+    }
+  for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  // --- V-graph (A + B B^T) on interior V-nodes
+  std::vector<ivec> vadj(nI);
+  std::vector<ivec> pv(nI);  // for P-nodes: interior V neighbours; for V-nodes: interior P neighbours
+  for (int i = 0; i < nI; i++)
+    for (int j : adj[i]) {
+      if (j >= nI) continue;
+      if (lp.zero_diag[i] != lp.zero_diag[j]) pv[i].push_back(j);
+      else if (!lp.zero_diag[i]) vadj[i].push_back(j);
+    }
+  for (int p = 0; p < nI; p++)
+    if (lp.zero_diag[p])
+      for (int a : pv[p]) for (int b : pv[p]) if (a != b) vadj[a].push_back(b);
+  for (auto& a : vadj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  // --- nested dissection of the V-nodes
+  NdCtx c;
+  c.vadj = &vadj; c.coord = &lp.coord; c.leaf = std::max(leaf_size, 1);
+  c.side.assign(nI, 0);
+  ivec vnodes;
+  for (int i = 0; i < nI; i++) if (!lp.zero_diag[i]) vnodes.push_back(i);
+  nd_recurse(c, vnodes);
+  // --- attach every P-node behind a V-node that grounds it (union-find over pressures;
+  //     the id nI stands for "boundary / separator / no second pressure")
+  ivec uf(nI + 1);
+  std::iota(uf.begin(), uf.end(), 0);
+  auto find = [&](int x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
+  ivec cont(nI + 1, 0);
+  for (int p = 0; p < nI; p++) if (lp.zero_diag[p]) cont[p] = (int)pv[p].size();
+  std::vector<char> pdone(nI, 0);
+  P.perm.clear();
+  std::vector<std::pair<int, int>> sn;  // supernodes as [begin,end) elimination positions
+  for (auto& s : c.snodes) {
+    const int b = (int)P.perm.size();
+    for (int t = s.first; t < s.second; t++) {
+      const int v = c.order[t];
+      P.perm.push_back(v);
+      HYMLS_CHECK(pv[v].size() <= 2, -4, "not an F-matrix: a velocity node couples to more than two pressures");
+      int g1 = pv[v].size() > 0 ? find(pv[v][0]) : nI;
+      int g2 = pv[v].size() > 1 ? find(pv[v][1]) : nI;
+      if (g1 == g2) continue;
+      int elim;
+      if (g1 == nI) { elim = g2; uf[g2] = nI; }
+      else if (g2 == nI) { elim = g1; uf[g1] = nI; }
+      else if (cont[g2] > cont[g1]) { elim = g1; uf[g1] = g2; cont[g2] = cont[g1] + cont[g2] - 2; }
+      else { elim = g2; uf[g2] = g1; cont[g1] = cont[g1] + cont[g2] - 2; }
+      pdone[elim] = 1;
+      P.perm.push_back(elim);
+    }
+    if ((int)P.perm.size() > b) sn.emplace_back(b, (int)P.perm.size());
+  }
+  for (int p = 0; p < nI; p++)
+    HYMLS_CHECK(!lp.zero_diag[p] || pdone[p], -4,
+                "structurally singular interior block: a zero-diagonal node cannot be paired with a velocity");
+  HYMLS_CHECK((int)P.perm.size() == nI, -3, "ordering lost nodes");
+  P.iperm.assign(nI, -1);
+  for (int i = 0; i < nI; i++) P.iperm[P.perm[i]] = i;
+  // --- cap the supernode width (chains of panels)
+  std::vector<std::pair<int, int>> sn2;
+  for (auto& s : sn)
+    for (int b = s.first; b < s.second; b += max_width) sn2.emplace_back(b, std::min(b + max_width, s.second));
+  sn.swap(sn2);
+  const int nf = (int)sn.size();
+  ivec sn_of(nI);
+  for (int s = 0; s < nf; s++) for (int t = sn[s].first; t < sn[s].second; t++) sn_of[t] = s;
+  auto pos_of = [&](int node) { return node < nI ? P.iperm[node] : node; };  // separators keep nI + id
+  // --- symbolic factorisation on the given supernode partition
+  P.fronts.resize(nf);
+  std::vector<ivec> kids(nf);
+  std::vector<ivec> rows(nf);
+  ivec mark(n, -1);
+  for (int s = 0; s < nf; s++) {
+    Front& F = P.fronts[s];
+    F.c0 = sn[s].first; F.w = sn[s].second - sn[s].first;
+    const int cend = F.c0 + F.w;
+    ivec& R = rows[s];
+    for (int t = F.c0; t < cend; t++)
+      for (int j : adj[P.perm[t]]) {
+        const int pj = pos_of(j);
+        if (pj >= cend && mark[pj] != s) { mark[pj] = s; R.push_back(pj); }
+      }
+    for (int ch : kids[s])
+      for (int pj : rows[ch])
+        if (pj >= cend && mark[pj] != s) { mark[pj] = s; R.push_back(pj); }
+    std::sort(R.begin(), R.end());
+    F.ri = (int)(std::lower_bound(R.begin(), R.end(), nI) - R.begin());
+    F.rs = (int)R.size() - F.ri;
+    F.parent = (F.ri > 0) ? sn_of[R[0]] : -1;
+    if (F.parent >= 0) kids[F.parent].push_back(s);
+  }
+  // --- levels
+  int maxlev = 0;
+  for (int s = 0; s < nf; s++) {
+    int lv = 0;
+    for (int ch : kids[s]) lv = std::max(lv, P.fronts[ch].level + 1);
+    P.fronts[s].level = lv;
+    maxlev = std::max(maxlev, lv);
+  }
+  P.levels.assign(nf ? maxlev + 1 : 0, ivec());
+  for (int s = 0; s < nf; s++) P.levels[P.fronts[s].level].push_back(s);
+  // --- index lists, offsets
+  int64_t foff = 0, fac = 0;
+  int32_t coff = 0;
+  for (int s = 0; s < nf; s++) {
+    Front& F = P.fronts[s];
+    F.idx_off = (int32_t)P.fidx.size();
+    for (int t = 0; t < F.w; t++) P.fidx.push_back(F.c0 + t);
+    P.fidx.insert(P.fidx.end(), rows[s].begin(), rows[s].end());
+    F.child_begin = (int32_t)P.children.size();
+    P.children.insert(P.children.end(), kids[s].begin(), kids[s].end());
+    F.child_end = (int32_t)P.children.size();
+    const int64_t m = F.m();
+    F.f_off = foff; foff += m * m;
+    F.lp_off = fac; fac += (int64_t)(F.w + F.ri) * F.w;
+    F.q_off = fac; fac += (int64_t)F.w * F.ri;
+    F.c_off = coff; coff += F.ri;
+    P.max_front = std::max<int32_t>(P.max_front, (int32_t)m);
+    P.max_solve_rows = std::max<int32_t>(P.max_solve_rows, F.w + F.ri);
+    P.nnz_factor += (int64_t)F.w * F.w + 2LL * F.w * F.ri;
+    const double w = F.w, r = F.ri + F.rs;
+    P.flops_factor += (int64_t)(2.0 / 3.0 * w * w * w + 2.0 * w * w * r + 2.0 * w * r * r);
+  }
+  P.scratch_size = foff; P.factor_size = fac; P.contrib_size = coff;
+  // --- relative maps (update rows -> position in the parent's index list / separator id)
+  ivec where(n, -1);
+  for (int s = 0; s < nf; s++) P.fronts[s].rel_off = -1;
+  {
+    int32_t roff = 0;
+    for (int s = 0; s < nf; s++) { P.fronts[s].rel_off = roff; roff += P.fronts[s].ri + P.fronts[s].rs; }
+    P.rel.assign(roff, -1);
+  }
+  for (int p = 0; p < nf; p++) {
+    const Front& Fp = P.fronts[p];
+    for (int t = 0; t < Fp.m(); t++) where[P.fidx[Fp.idx_off + t]] = t;
+    for (int e = Fp.child_begin; e < Fp.child_end; e++) {
+      const Front& Fc = P.fronts[P.children[e]];
+      for (int t = 0; t < Fc.ri + Fc.rs; t++) {
+        const int pj = P.fidx[Fc.idx_off + Fc.w + t];
+        HYMLS_CHECK(where[pj] >= 0, -3, "symbolic: child row missing in parent front");
+        P.rel[Fc.rel_off + t] = where[pj];
+      }
+    }
+    for (int t = 0; t < Fp.m(); t++) where[P.fidx[Fp.idx_off + t]] = -1;
+  }
+  for (int s = 0; s < nf; s++) {
+    const Front& F = P.fronts[s];
+    if (F.parent >= 0) continue;
+    for (int t = 0; t < F.rs; t++) P.rel[F.rel_off + t] = P.fidx[F.idx_off + F.w + t] - nI;
+  }
+  // --- matrix entries -> fronts
+  struct Ent { int32_t front, id, pos; double w; };
+  std::vector<Ent> ents;
+  ents.reserve(lp.col.size());
+  {
+    // per-front position lookup: process entries grouped by front via counting sort
+    std::vector<ivec> byfront(nf + 1);
+    for (int i = 0; i < n; i++)
+      for (int e = lp.rowptr[i]; e < lp.rowptr[i + 1]; e++) {
+        const int pi = pos_of(i), pj = pos_of(lp.col[e]);
+        const int pm = std::min(pi, pj);
+        byfront[pm < nI ? sn_of[pm] : nf].push_back(e);
+      }
+    ivec rowof(lp.col.size());
+    for (int i = 0; i < n; i++) for (int e = lp.rowptr[i]; e < lp.rowptr[i + 1]; e++) rowof[e] = i;
+    for (int s = 0; s <= nf; s++) {
+      if (s < nf) {
+        const Front& F = P.fronts[s];
+        for (int t = 0; t < F.m(); t++) where[P.fidx[F.idx_off + t]] = t;
+        for (int e : byfront[s]) {
+          const int a = where[pos_of(rowof[e])], b = where[pos_of(lp.col[e])];
+          HYMLS_CHECK(a >= 0 && b >= 0, -3, "symbolic: matrix entry outside its front");
+          ents.push_back({s, e, a + F.m() * b, lp.weight.empty() ? 1.0 : lp.weight[e]});
+        }
+        for (int t = 0; t < F.m(); t++) where[P.fidx[F.idx_off + t]] = -1;
+      } else {
+        for (int e : byfront[s])
+          ents.push_back({s, e, (rowof[e] - nI) + nS * (lp.col[e] - nI), lp.weight.empty() ? 1.0 : lp.weight[e]});
+      }
+    }
+  }
+  P.ent_id.resize(ents.size()); P.ent_pos.resize(ents.size()); P.ent_w.resize(ents.size());
+  for (int s = 0; s < nf; s++) P.fronts[s].ent_begin = P.fronts[s].ent_end = 0;
+  {
+    int cur = -1;
+    for (size_t k = 0; k < ents.size(); k++) {
+      P.ent_id[k] = ents[k].id; P.ent_pos[k] = ents[k].pos; P.ent_w[k] = ents[k].w;
+      if (ents[k].front != cur) {
+        cur = ents[k].front;
+        if (cur < nf) P.fronts[cur].ent_begin = (int32_t)k; else P.s_ent_begin = (int32_t)k;
+      }
+      if (cur < nf) P.fronts[cur].ent_end = (int32_t)k + 1;
+    }
+    if (cur < nf || ents.empty()) P.s_ent_begin = (int32_t)ents.size();
+  }
+  return P;
+}
+
+}  // namespace hymls

@@ -1,0 +1,149 @@
+/* hymls_mi.h -- C ABI of the MI355X-native HYMLS preconditioner hot path.
+ *
+ * Drop-in boundary for HYMLS::Preconditioner (Ifpack_Preconditioner /
+ * Epetra_Operator surface, reference src/HYMLS_Preconditioner.hpp:56-254),
+ * modelled on the reference's own flat handle API, the MATLAB MEX wrapper
+ * (reference matlab/HYMLS_init.cpp, HYMLS_apply.cpp, HYMLS_free.cpp).
+ *
+ * Conventions
+ *   - all floating point data is FP64, all indices int32 (hymls_gidx = int,
+ *     reference src/HYMLS_config.h.in without HYMLS_LONG_LONG),
+ *   - vectors are column-major multivectors with leading dimension ld, in the
+ *     user's row ordering (OperatorDomainMap == OperatorRangeMap ==
+ *     K.RowMatrixRowMap, reference src/HYMLS_Preconditioner.hpp:182-186);
+ *     GID of row i is i (gid = ((k*ny+j)*nx+i)*dof+var, src/HYMLS_Tools.cpp:691-723),
+ *   - every function returns 0 on success and a negative code on error
+ *     (Ifpack convention; -1 = not initialized/computed, -2 = bad argument,
+ *     -3 = device/runtime failure, -4 = numerically singular block,
+ *     -99 = not implemented, as the reference's Apply()); no exception
+ *     crosses the ABI; hymls_mi_last_error() holds the message,
+ *   - a handle is not re-entrant (like the reference: mutable scratch,
+ *     src/HYMLS_Preconditioner.hpp:292-305).
+ */
+#ifndef HYMLS_MI_H
+#define HYMLS_MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hymls_mi hymls_mi_t;
+
+/* Parameter block = the keys of the reference's "Problem" and "Preconditioner"
+ * sublists that change the hot path (src/HYMLS_BasePartitioner.cpp:31-252,
+ * src/HYMLS_Preconditioner.cpp:135-276).  -1 selects the reference default. */
+typedef struct hymls_mi_params {
+  int32_t nx, ny, nz;           /* "nx","ny","nz" */
+  int32_t dim;                  /* "Dimension" (2|3) */
+  int32_t equations;            /* "Equations": 0 = Laplace, 1 = Stokes-C */
+  int32_t dof;                  /* "Degrees of Freedom" (-1: from equations) */
+  int32_t sx, sy, sz;           /* "Separator Length[ (x|y|z)]" */
+  int32_t cx, cy, cz;           /* "Coarsening Factor[ (x|y|z)]" */
+  int32_t levels;               /* "Number of Levels" (0-based as in the XML) */
+  int32_t partitioner;          /* "Partitioner": 0 = Cartesian, 1 = Skew Cartesian */
+  int32_t retain_nodes;         /* "Retain Nodes" */
+  int32_t retain_pressures;     /* "Retained Pressure Nodes" */
+  int32_t link_velocities;      /* "Eliminate Velocities Together" (default 1) */
+  int32_t link_retained;        /* "Eliminate Retained Nodes Together" (default 1) */
+  int32_t fix_pressure_level;   /* "Fix Pressure Level" (default 1) */
+  int32_t nfix;                 /* explicit "Fix GID n" entries (0: derive) */
+  int32_t fix_gid[4];
+  int32_t variable_type[8];     /* per dof: 0 Laplace/Velocity_V,1 U,2 V,3 W,4 Pressure,5 Interior; used if dof given and equations<0 */
+} hymls_mi_params;
+
+/* fill *p with the reference defaults (everything -1 / default flags). */
+void hymls_mi_default_params(hymls_mi_params* p);
+
+/* HYMLS::Preconditioner ctor (src/HYMLS_Preconditioner.hpp:80-84).
+ * device: HIP device ordinal. */
+int hymls_mi_create(hymls_mi_t** h, const hymls_mi_params* p, int device);
+
+/* the matrix K (Epetra_CrsMatrix view): n rows, CSR, global column ids,
+ * host pointers; copied.  Replaces the ctor's K argument and SetMatrix
+ * (src/HYMLS_Preconditioner.hpp:244-254). */
+int hymls_mi_set_matrix_csr(hymls_mi_t* h, int64_t nrows, const int32_t* rowptr,
+                            const int32_t* colind, const double* val);
+
+/* optional test vector (ctor argument testVector; default all ones,
+ * src/HYMLS_Preconditioner.cpp:781-787). Host pointer, n entries. */
+int hymls_mi_set_testvector(hymls_mi_t* h, const double* v);
+
+/* Ifpack_Preconditioner::Initialize / Compute
+ * (src/HYMLS_Preconditioner.cpp:279-394, 400-517). */
+int hymls_mi_initialize(hymls_mi_t* h);
+int hymls_mi_compute(hymls_mi_t* h);
+
+/* Ifpack_Preconditioner::ApplyInverse(B, X) (src/HYMLS_Preconditioner.cpp:594-605,
+ * 930-1070).  B, X: nvec columns, leading dimensions ldb/ldx.
+ * on_device != 0: B and X are device pointers on the handle's device and the
+ * call is asynchronous on the handle's stream (see hymls_mi_stream). */
+int hymls_mi_apply_inverse(hymls_mi_t* h, const double* B, int64_t ldb,
+                           double* X, int64_t ldx, int nvec, int on_device);
+
+/* Epetra_Operator::Apply: not implemented in the reference (returns -1,
+ * src/HYMLS_Preconditioner.cpp:585-592); same here. */
+int hymls_mi_apply(hymls_mi_t* h, const double* X, double* Y);
+
+/* y = K x on the device copy of K (helper for an on-device Krylov caller;
+ * the reference's caller does this through Epetra_CrsMatrix::Apply). */
+int hymls_mi_matvec(hymls_mi_t* h, const double* X, double* Y, int on_device);
+
+/* state queries (IsInitialized / IsComputed / Num* / *Time,
+ * src/HYMLS_Preconditioner.cpp:396-398,519-523,612-717). */
+int hymls_mi_is_initialized(const hymls_mi_t* h);
+int hymls_mi_is_computed(const hymls_mi_t* h);
+int hymls_mi_num_initialize(const hymls_mi_t* h);
+int hymls_mi_num_compute(const hymls_mi_t* h);
+int hymls_mi_num_apply_inverse(const hymls_mi_t* h);
+double hymls_mi_initialize_time(const hymls_mi_t* h);
+double hymls_mi_compute_time(const hymls_mi_t* h);
+double hymls_mi_apply_inverse_time(const hymls_mi_t* h);
+
+/* level banner data ("SIZE OF A / SIZE OF S", src/HYMLS_Preconditioner.cpp:362-371).
+ * level = 0..num_levels-1; the last level is the coarse direct solve. */
+int hymls_mi_num_levels(const hymls_mi_t* h);
+int64_t hymls_mi_level_size(const hymls_mi_t* h, int level);    /* SIZE OF A */
+int64_t hymls_mi_level_schur_size(const hymls_mi_t* h, int level); /* SIZE OF S */
+int64_t hymls_mi_level_num_subdomains(const hymls_mi_t* h, int level);
+
+/* measurement support: algorithmic bytes one ApplyInverse (1 rhs)
+ * streams; which = 0 total, 1 interior factor panels (both sweeps, both solves),
+ * 2 A12+A21, 3 separator blocks + OT, 4 coarse/next levels, 5 vectors. */
+double hymls_mi_apply_bytes(const hymls_mi_t* h, int which);
+/* device seconds spent in the last ApplyInverse, per phase (hipEvent):
+ * which = 0 total, 1 interior solves, 2 SpMV, 3 Schur (OT+blocks), 4 coarse. */
+double hymls_mi_last_apply_seconds(const hymls_mi_t* h, int which);
+/* enable (1) / disable (0) per-phase event timing inside ApplyInverse. */
+int hymls_mi_set_profiling(hymls_mi_t* h, int on);
+/* the HIP stream (hipStream_t) every kernel of this handle is launched on. */
+void* hymls_mi_stream(const hymls_mi_t* h);
+
+/* partition introspection, used by the parity tests (what the reference's
+ * unit tests read through OverlappingPartitioner::GetInteriorGroup /
+ * GetSeparatorGroups, testSuite/unit_tests/HYMLS_OverlappingPartitioner.cpp).
+ * Counts first (out == NULL), then fill. Groups are concatenated:
+ *   group_ptr[num_groups+1], group_type[num_groups], nodes[group_ptr[num_groups]]. */
+int hymls_mi_get_interior(const hymls_mi_t* h, int level, int sd, int32_t* n, int32_t* nodes);
+int hymls_mi_get_separator_groups(const hymls_mi_t* h, int level, int sd, int32_t* num_groups,
+                                  int32_t* group_ptr, int32_t* group_type,
+                                  int32_t* owned, int32_t* nodes);
+
+/* input generators (reference src/GaleriExt_Stokes3D.h:89-285, Galeri Laplace3D
+ * via src/HYMLS_MainUtils.cpp:260-348).  Two-call protocol: rowptr==NULL returns
+ * nnz in *nnz; otherwise fills rowptr[n+1], colind[nnz], val[nnz]. */
+int hymls_mi_generate_matrix(int equations, int nx, int ny, int nz, double a, double b,
+                             int64_t* nrows, int64_t* nnz, int32_t* rowptr, int32_t* colind,
+                             double* val);
+/* create_testvector (reference src/HYMLS_MainUtils.cpp:208-258). */
+int hymls_mi_generate_testvector(int64_t nrows, const int32_t* rowptr, const int32_t* colind,
+                                 const double* val, double* tv);
+
+const char* hymls_mi_last_error(const hymls_mi_t* h);
+void hymls_mi_destroy(hymls_mi_t* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYMLS_MI_H */

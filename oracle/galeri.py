@@ -1,0 +1,156 @@
+"""Test-matrix generators (oracle side): restatement of the reference's GaleriExt
+generators for the non-periodic C-grid case.  TEST INFRASTRUCTURE ONLY.
+
+Reference:
+  src/GaleriExt_Stokes3D.h:89-285   (Stokes3D, grid_type 'C')
+  src/GaleriExt_Darcy3D.h:45-176    (Darcy3D)
+  src/GaleriExt_Periodic.cpp:36-66  (GetNeighboursCartesian3d; -1 outside box)
+  src/HYMLS_MainUtils.cpp:260-348   (create_matrix: Stokes a=nx^2, b=1; Laplace scaled by -1)
+  Trilinos Galeri Cross3D semantics (not in /root/reference):
+  diag a, neighbours b..g, missing neighbours omitted, cell id=(k*ny+j)*nx+i.
+
+GID convention: gid = cell*dof + var (src/HYMLS_Tools.cpp:691-723).
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+def _cells(nx, ny, nz):
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    return i.ravel(), j.ravel(), k.ravel()
+
+
+def _neigh(nx, ny, nz):
+    """left,right,lower,upper,below,above cell ids (-1 outside), GaleriExt_Periodic.cpp:36-66."""
+    i, j, k = _cells(nx, ny, nz)
+    c = (k * ny + j) * nx + i
+    left = np.where(i > 0, c - 1, -1)
+    right = np.where(i < nx - 1, c + 1, -1)
+    lower = np.where(j > 0, c - nx, -1)
+    upper = np.where(j < ny - 1, c + nx, -1)
+    below = np.where(k > 0, c - nx * ny, -1)
+    above = np.where(k < nz - 1, c + nx * ny, -1)
+    return c, (left, right, lower, upper, below, above)
+
+
+def laplace3d(nx, ny, nz, scale=-1.0):
+    """Galeri 'Laplace3D' = Cross3D(6,-1,...), scaled by -1 as in create_matrix
+    (src/HYMLS_MainUtils.cpp:340-345).  dof = 1."""
+    c, nb = _neigh(nx, ny, nz)
+    rows = [c]
+    cols = [c]
+    vals = [np.full(c.size, 6.0)]
+    for n in nb:
+        m = n >= 0
+        rows.append(c[m])
+        cols.append(n[m])
+        vals.append(np.full(m.sum(), -1.0))
+    A = sp.coo_matrix((np.concatenate(vals) * scale, (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(c.size, c.size)).tocsr()
+    A.sort_indices()
+    return A
+
+
+def darcy3d(nx, ny, nz, a, b):
+    """GaleriExt::Darcy3D (src/GaleriExt_Darcy3D.h:45-176): A=diag(a) on u,v,w,
+    grad entries (-b at p_here, +b at p_next), div rows with c=-b."""
+    dof = 4
+    c, (left, right, lower, upper, below, above) = _neigh(nx, ny, nz)
+    N = c.size * dof
+    rows, cols, vals = [], [], []
+    cc = -b
+
+    def add(r, cl, v):
+        rows.append(r)
+        cols.append(cl)
+        vals.append(np.full(r.size, v) if np.isscalar(v) else v)
+
+    for var, nxt in ((0, right), (1, upper), (2, above)):
+        add(c * dof + var, c * dof + var, a)
+        m = nxt >= 0
+        add(c[m] * dof + var, c[m] * dof + 3, -b)
+        add(c[m] * dof + var, nxt[m] * dof + 3, b)
+    for var, nxt, prv in ((0, right, left), (1, upper, lower), (2, above, below)):
+        m = nxt >= 0
+        add(c[m] * dof + 3, c[m] * dof + var, -cc)
+        m = prv >= 0
+        add(c[m] * dof + 3, prv[m] * dof + var, cc)
+    A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(N, N)).tocsr()
+    A.sort_indices()
+    return A
+
+
+def stokes3d(nx, ny, nz, a=None, b=1.0):
+    """GaleriExt::Stokes3D, C grid, no periodicity (src/GaleriExt_Stokes3D.h:89-285).
+    Default a = nx*nx, b = 1 as in create_matrix (src/HYMLS_MainUtils.cpp:322-323).
+    Explicit zeros written by the reference (removed wall couplings) are dropped
+    here: the fixture test compares by matvec, as the reference's own test does."""
+    if a is None:
+        a = float(nx * nx)
+    dof = 4
+    c, (left, right, lower, upper, below, above) = _neigh(nx, ny, nz)
+    ncell = c.size
+    N = ncell * dof
+    rows, cols, vals = [], [], []
+
+    def add(r, cl, v):
+        r = np.asarray(r)
+        rows.append(r)
+        cols.append(np.asarray(cl))
+        vals.append(np.full(r.size, float(v)) if np.isscalar(v) else np.asarray(v, dtype=float))
+
+    def nxt_of(arr, n):
+        out = np.full(ncell, -1)
+        m = n >= 0
+        out[m] = arr[n[m]]
+        return out
+
+    # Darcy3D(map, 0.0, -b): grad entries +b at p_here, -b at p_next; div rows c = b
+    for var, nxt, prv in ((0, right, left), (1, upper, lower), (2, above, below)):
+        m = nxt >= 0
+        add(c[m] * dof + var, c[m] * dof + 3, b)
+        add(c[m] * dof + var, nxt[m] * dof + 3, -b)
+        add(c[m] * dof + 3, c[m] * dof + var, -b)
+        m = prv >= 0
+        add(c[m] * dof + 3, prv[m] * dof + var, b)
+
+    # velocity rows: -a * Cross3D(6,-1) with wall corrections (Stokes3D.h:150-262)
+    tang = {0: ((lower, upper), (below, above)),
+            1: ((left, right), (below, above)),
+            2: ((left, right), (lower, upper))}
+    nrm = {0: right, 1: upper, 2: above}
+    allnb = (left, right, lower, upper, below, above)
+    for var in range(3):
+        nx_ = nrm[var]
+        nxnx = nxt_of(nx_, nx_)  # "rightright" etc.
+        wall = nx_ < 0  # velocity sits on the wall: Dirichlet row, diag = 1
+        add(c[wall] * dof + var, c[wall] * dof + var, 1.0)
+        inner = ~wall
+        add_diag = np.zeros(ncell)
+        for (lo, hi) in tang[var]:
+            add_diag += np.where((lo < 0) | (hi < 0), a, 0.0)
+        add(c[inner] * dof + var, c[inner] * dof + var, -(6.0 * a + add_diag[inner]))
+        for n in allnb:
+            m = inner & (n >= 0)
+            # coupling to the velocity on the wall is removed (Stokes3D.h:199-206)
+            if n is nx_:
+                m = m & ~((nx_ >= 0) & (nxnx < 0))
+            add(c[m] * dof + var, n[m] * dof + var, a)
+    A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(N, N)).tocsr()
+    A.sort_indices()
+    return A
+
+
+def create_testvector(A):
+    """create_testvector (src/HYMLS_MainUtils.cpp:208-258), Stokes-C / Laplace:
+    all ones, zero on rows whose only nonzero is the diagonal."""
+    A = A.tocsr()
+    t = np.ones(A.shape[0])
+    rows = np.repeat(np.arange(A.shape[0]), np.diff(A.indptr))
+    offd = (A.indices != rows) & (A.data != 0.0)
+    has_off = np.zeros(A.shape[0], dtype=bool)
+    has_off[rows[offd]] = True
+    t[~has_off] = 0.0
+    return t

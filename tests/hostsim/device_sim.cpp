@@ -1,0 +1,264 @@
+// device_sim.cpp -- TEST-ONLY host simulator of the device boundary (hymls::dev).
+//
+// Implements every launcher of hymls_amd/csrc/device.hpp with plain sequential loops on
+// host memory so that the host-side index plans (partition, ordering, assembly tree,
+// gather/pull lists) can be validated end-to-end on a machine without a GPU.  It is linked
+// ONLY into tests/hostsim/libhymls_mi_hostsim.so; the product library libhymls_mi.so
+// contains the HIP implementation (device_hip.hip) and no CPU path.
+#include "device.hpp"
+#include <cstring>
+#include <chrono>
+
+namespace hymls {
+namespace dev {
+
+void init(int) {}
+void* stream() { return nullptr; }
+void* alloc(size_t bytes) { return std::calloc(std::max<size_t>(bytes, 8), 1); }
+void free(void* p) { std::free(p); }
+void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
+void zero(void* d, size_t n) { std::memset(d, 0, n); }
+void sync() {}
+size_t mem_free() { return (size_t)1 << 40; }
+static std::chrono::steady_clock::time_point t0[16];
+void timer_start(int id) { t0[id] = std::chrono::steady_clock::now(); }
+double timer_stop(int id) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0[id]).count(); }
+
+void gather(int64_t n, const int32_t* idx, const double* src, double* dst) { for (int64_t i = 0; i < n; i++) dst[i] = src[idx[i]]; }
+void scatter(int64_t n, const int32_t* idx, const double* src, double* dst) { for (int64_t i = 0; i < n; i++) dst[idx[i]] = src[i]; }
+void axpby(int64_t n, double a, const double* x, double b, double* y) { for (int64_t i = 0; i < n; i++) y[i] = a * x[i] + b * y[i]; }
+void scale_copy(int64_t n, double a, const double* x, double* y) { for (int64_t i = 0; i < n; i++) y[i] = a * x[i]; }
+void spmv(int32_t nrows, const int32_t* rp, const int32_t* col, const double* val, const double* x, double* y,
+          double alpha, double beta) {
+  for (int i = 0; i < nrows; i++) {
+    double s = 0;
+    for (int e = rp[i]; e < rp[i + 1]; e++) s += val[e] * x[col[e]];
+    y[i] = alpha * s + (beta == 0.0 ? 0.0 : beta * y[i]);
+  }
+}
+void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out) {
+  for (int64_t e = 0; e < n; e++) { double s = 0; for (int64_t t = ptr[e]; t < ptr[e + 1]; t++) s += in[idx[t]]; out[e] = s; }
+}
+void pull_sum_blocks(int64_t blen, int32_t nblk, const int64_t* ptr, const int64_t* base, const double* in, double* out) {
+  for (int B = 0; B < nblk; B++)
+    for (int64_t k = 0; k < blen; k++) { double s = 0; for (int64_t t = ptr[B]; t < ptr[B + 1]; t++) s += in[base[t] + k]; out[(int64_t)B * blen + k] = s; }
+}
+
+void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const double* kval) {
+  const int64_t n2 = (int64_t)P.nS * P.nS;
+  for (int s = 0; s < nbc; s++) {
+    double* S = B.sblock + (int64_t)s * n2;
+    std::memset(S, 0, n2 * sizeof(double));
+    const int32_t* src = B.src + (int64_t)(b0 + s) * P.nent;
+    for (int e = P.s_ent_begin; e < P.s_ent_end; e++) S[P.ent_pos[e]] += P.ent_w[e] * kval[src[P.ent_id[e]]];
+  }
+}
+
+void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, int32_t b0, int32_t nbc,
+                  const double* kval) {
+  for (int slot = 0; slot < nbc; slot++)
+    for (int q = 0; q < count; q++) {
+      const int b = b0 + slot;
+      const FrontD& F = P.fronts[list[q]];
+      const int w = F.w, ri = F.ri, rs = F.rs, m = w + ri + rs;
+      double* sc = B.scratch + (int64_t)slot * P.scratch_size;
+      double* A = sc + F.f_off;
+      std::memset(A, 0, (size_t)m * m * sizeof(double));
+      const int32_t* src = B.src + (int64_t)b * P.nent;
+      for (int e = F.ent_begin; e < F.ent_end; e++) A[P.ent_pos[e]] += P.ent_w[e] * kval[src[P.ent_id[e]]];
+      for (int ce = F.child_begin; ce < F.child_end; ce++) {
+        const FrontD& C = P.fronts[P.children[ce]];
+        const int mc = C.w + C.ri + C.rs, rc = C.ri + C.rs;
+        const double* Ac = sc + C.f_off;
+        const int32_t* rel = P.rel + C.rel_off;
+        for (int bb = 0; bb < rc; bb++)
+          for (int a = 0; a < rc; a++) A[rel[a] + (int64_t)m * rel[bb]] += Ac[(C.w + a) + (int64_t)mc * (C.w + bb)];
+      }
+      for (int k = 0; k < w; k++) {
+        const double piv = A[k + (int64_t)m * k];
+        if (piv == 0.0 || !std::isfinite(piv)) *B.flag = 1;
+        const double ip = 1.0 / piv;
+        for (int i = k + 1; i < m; i++) A[i + (int64_t)m * k] *= ip;
+        for (int j = k + 1; j < m; j++) {
+          const double u = A[k + (int64_t)m * j];
+          if (u != 0.0) for (int i = k + 1; i < m; i++) A[i + (int64_t)m * j] -= A[i + (int64_t)m * k] * u;
+        }
+      }
+      double* fac = B.factor + (int64_t)b * P.factor_size;
+      double* Lp = fac + F.lp_off;
+      double* Q = fac + F.q_off;
+      const int ld = w + ri;
+      auto Lk = [&](int i, int j) { return A[i + (int64_t)m * j]; };
+      for (int t = 0; t < w; t++) {  // Linv column t (strictly lower part stored)
+        for (int i = t + 1; i < w; i++) {
+          double s = Lk(i, t);  // j = t term: L[i,t] * z_t (z_t = 1)
+          for (int j = t + 1; j < i; j++) s += Lk(i, j) * Lp[j + (int64_t)ld * t];
+          Lp[i + (int64_t)ld * t] = -s;
+        }
+      }
+      for (int t = 0; t < w; t++) {  // Uinv column t (upper incl. diagonal)
+        Lp[t + (int64_t)ld * t] = 1.0 / Lk(t, t);
+        for (int i = t - 1; i >= 0; i--) {
+          double s = 0;
+          for (int j = i + 1; j <= t; j++) s += Lk(i, j) * Lp[j + (int64_t)ld * t];
+          Lp[i + (int64_t)ld * t] = -s / Lk(i, i);
+        }
+      }
+      for (int i = 0; i < ri; i++)  // PL row i = L21[i,:] L11^{-1}
+        for (int k = w - 1; k >= 0; k--) {
+          double s = Lk(w + i, k);
+          for (int j = k + 1; j < w; j++) s -= Lp[(w + i) + (int64_t)ld * j] * Lk(j, k);
+          Lp[(w + i) + (int64_t)ld * k] = s;
+        }
+      for (int j = 0; j < ri; j++)  // QU column j = U11^{-1} U12[:,j]
+        for (int i = w - 1; i >= 0; i--) {
+          double s = Lk(i, w + j);
+          for (int k = i + 1; k < w; k++) s -= Lk(i, k) * Q[k + (int64_t)w * j];
+          Q[i + (int64_t)w * j] = s / Lk(i, i);
+        }
+      if (F.parent < 0 && rs > 0) {
+        double* S = B.sblock + (int64_t)slot * P.nS * P.nS;
+        const int32_t* rel = P.rel + F.rel_off;
+        for (int bb = 0; bb < rs; bb++)
+          for (int a = 0; a < rs; a++) S[rel[ri + a] + (int64_t)P.nS * rel[ri + bb]] += A[(w + ri + a) + (int64_t)m * (w + ri + bb)];
+      }
+    }
+}
+
+void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
+  std::vector<double> f;
+  for (int b = 0; b < B.nb; b++)
+    for (int q = 0; q < count; q++) {
+      const FrontD& F = P.fronts[list[q]];
+      const int w = F.w, ri = F.ri, ld = w + ri;
+      f.assign(ld, 0.0);
+      double* xb = x + B.xoff[b];
+      double* cb = B.contrib + (int64_t)b * P.contrib_size;
+      for (int j = 0; j < w; j++) f[j] = xb[F.c0 + j];
+      for (int ce = F.child_begin; ce < F.child_end; ce++) {
+        const FrontD& C = P.fronts[P.children[ce]];
+        const int32_t* rel = P.rel + C.rel_off;
+        for (int k = 0; k < C.ri; k++) f[rel[k]] += cb[C.c_off + k];
+      }
+      const double* Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off;
+      for (int i = 0; i < w; i++) {
+        double s = f[i];
+        for (int k = 0; k < i; k++) s += Lp[i + (int64_t)ld * k] * f[k];
+        xb[F.c0 + i] = s;
+      }
+      for (int i = 0; i < ri; i++) {
+        double s = f[w + i];
+        for (int k = 0; k < w; k++) s -= Lp[(w + i) + (int64_t)ld * k] * f[k];
+        cb[F.c_off + i] = s;
+      }
+    }
+}
+
+void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
+  std::vector<double> g, out;
+  for (int b = 0; b < B.nb; b++)
+    for (int q = 0; q < count; q++) {
+      const FrontD& F = P.fronts[list[q]];
+      const int w = F.w, ri = F.ri, ld = w + ri;
+      double* xb = x + B.xoff[b];
+      g.resize(ld); out.resize(w);
+      for (int k = 0; k < w; k++) g[k] = xb[F.c0 + k];
+      for (int k = 0; k < ri; k++) g[w + k] = xb[P.fidx[F.idx_off + w + k]];
+      const double* fac = B.factor + (int64_t)b * P.factor_size;
+      const double* Lp = fac + F.lp_off;
+      const double* Q = fac + F.q_off;
+      for (int i = 0; i < w; i++) {
+        double s = 0;
+        for (int k = i; k < w; k++) s += Lp[i + (int64_t)ld * k] * g[k];
+        for (int k = 0; k < ri; k++) s -= Q[i + (int64_t)w * k] * g[w + k];
+        out[i] = s;
+      }
+      for (int i = 0; i < w; i++) xb[F.c0 + i] = out[i];
+    }
+}
+
+void ot_apply(int32_t ng, const int32_t* gptr, const double* w, double* x) {
+  for (int g = 0; g < ng; g++) {
+    double s = 0;
+    for (int i = gptr[g]; i < gptr[g + 1]; i++) s += w[i] * x[i];
+    for (int i = gptr[g]; i < gptr[g + 1]; i++) x[i] = 2.0 * w[i] * s - x[i];
+  }
+}
+
+static void hh_rows(double* X, int64_t ld, int ncols, int pos, int n, const double* vin) {
+  // Householder::Apply semantics (reference src/HYMLS_Householder.cpp:38-80) on rows pos..pos+n
+  std::vector<double> v(vin, vin + n);
+  const double sg = v[0] < 0 ? -1.0 : (v[0] > 0 ? 1.0 : 0.0);
+  double nrm = 0;
+  for (double& t : v) { t *= sg; nrm += t * t; }
+  nrm = std::sqrt(nrm);
+  const double v1 = v[0] + nrm;
+  if (std::abs(v1) < SMALL_ENTRY || nrm < SMALL_ENTRY) return;
+  const double fac1 = 1.0 / (nrm * v1);
+  for (int k = 0; k < ncols; k++) {
+    double* c = X + (int64_t)ld * k + pos;
+    double fac2 = nrm * c[0];
+    for (int i = 0; i < n; i++) fac2 += c[i] * v[i];
+    const double fac = fac1 * fac2;
+    c[0] = v1 * fac - c[0];
+    for (int i = 1; i < n; i++) c[i] = v[i] * fac - c[i];
+  }
+}
+
+void sblock_transform(int32_t nS, int32_t ng, const int32_t* gptr, const double* tv, double* sblock, int32_t nbc) {
+  std::vector<double> T((size_t)nS * nS);
+  for (int b = 0; b < nbc; b++) {
+    double* S = sblock + (int64_t)b * nS * nS;
+    const double* v = tv + (int64_t)b * nS;
+    for (int g = 0; g < ng; g++) hh_rows(S, nS, nS, gptr[g], gptr[g + 1] - gptr[g], v + gptr[g]);
+    for (int i = 0; i < nS; i++) for (int j = 0; j < nS; j++) T[j + (size_t)nS * i] = S[i + (size_t)nS * j];
+    for (int g = 0; g < ng; g++) hh_rows(T.data(), nS, nS, gptr[g], gptr[g + 1] - gptr[g], v + gptr[g]);
+    for (int i = 0; i < nS; i++) for (int j = 0; j < nS; j++) S[i + (size_t)nS * j] = T[j + (size_t)nS * i];
+  }
+}
+
+void sblock_extract(int32_t nS, int64_t npick, const int32_t* pick, const double* sblock, double* out,
+                    int64_t out_stride, int32_t nbc) {
+  for (int b = 0; b < nbc; b++)
+    for (int64_t k = 0; k < npick; k++) out[(int64_t)b * out_stride + k] = sblock[(int64_t)b * nS * nS + pick[k]];
+}
+
+void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag) {
+  std::vector<double> W((size_t)nb * 2 * nb);
+  for (int B = 0; B < nblk; B++) {
+    double* A = blocks + (int64_t)B * nb * nb;
+    // Gauss-Jordan with partial pivoting on [A | I], column-major with ld = nb, 2nb columns
+    for (int j = 0; j < nb; j++) for (int i = 0; i < nb; i++) { W[i + (size_t)nb * j] = A[i + (size_t)nb * j]; W[i + (size_t)nb * (nb + j)] = (i == j); }
+    for (int k = 0; k < nb; k++) {
+      int p = k; double best = std::abs(W[k + (size_t)nb * k]);
+      for (int i = k + 1; i < nb; i++) if (std::abs(W[i + (size_t)nb * k]) > best) { best = std::abs(W[i + (size_t)nb * k]); p = i; }
+      if (best == 0.0 || !std::isfinite(best)) { *flag = 1; break; }
+      if (p != k) for (int j = 0; j < 2 * nb; j++) std::swap(W[k + (size_t)nb * j], W[p + (size_t)nb * j]);
+      const double ip = 1.0 / W[k + (size_t)nb * k];
+      for (int j = 0; j < 2 * nb; j++) W[k + (size_t)nb * j] *= ip;
+      for (int i = 0; i < nb; i++) {
+        if (i == k) continue;
+        const double l = W[i + (size_t)nb * k];
+        if (l != 0.0) for (int j = 0; j < 2 * nb; j++) W[i + (size_t)nb * j] -= l * W[k + (size_t)nb * j];
+      }
+    }
+    for (int j = 0; j < nb; j++) for (int i = 0; i < nb; i++) A[i + (size_t)nb * j] = W[i + (size_t)nb * (nb + j)];
+  }
+}
+
+void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* ids, const double* x, double* y) {
+  for (int B = 0; B < nblk; B++) {
+    const double* M = binv + (int64_t)B * nb * nb;
+    const int32_t* id = ids + (int64_t)B * nb;
+    for (int i = 0; i < nb; i++) {
+      double s = 0;
+      for (int j = 0; j < nb; j++) s += M[i + (size_t)nb * j] * x[id[j]];
+      y[id[i]] = s;
+    }
+  }
+}
+
+}  // namespace dev
+}  // namespace hymls

@@ -42,6 +42,13 @@ def load_library(path=None):
         raise ImportError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). hymls_amd has no CPU fallback." % path)
+    if path == os.path.abspath(LIB_PATH):
+        # PyTorch-ROCm owns device memory/streams in this process: let it bring up its HIP
+        # runtime first so that both sides share one libamdhip64.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     H = C.c_void_p
     sig = {

@@ -52,6 +52,7 @@ struct PlanD {
   int32_t s_ent_begin, s_ent_end;
   int64_t scratch_size, factor_size;
   int32_t contrib_size;
+  int32_t max_solve_rows;   // max over fronts of w + ri (LDS vector of the solve kernels)
 };
 
 // a batch of subdomains of one class

@@ -83,6 +83,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   dplan.s_ent_begin = plan.s_ent_begin; dplan.s_ent_end = nent;
   dplan.scratch_size = plan.scratch_size; dplan.factor_size = plan.factor_size;
   dplan.contrib_size = plan.contrib_size;
+  dplan.max_solve_rows = std::max(plan.max_solve_rows, 1);
   for (auto& L : plan.levels) d_lists.push_back(keep(dev::upload(L)));
   const int64_t per = plan.scratch_size + (with_sblock ? (int64_t)plan.nS * plan.nS : 0);
   chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nb, budget / std::max<int64_t>(per, 1)));

@@ -1,0 +1,107 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+Tolerances: FP64, different LU (multifrontal without pivoting, product-form panels vs
+SuperLU/LAPACK in the oracle) => relative 2-norm difference of one ApplyInverse
+<= 1e-10 for exact (levels=0) configurations and <= 1e-8 multilevel."""
+import numpy as np
+import pytest
+
+from common import problem, xml_params, oracle_prec, product_prec, rel_diff
+from oracle import krylov
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # eq, n, sx, levels, cx, tol
+    ("Laplace", 8, 4, 0, -1, 1e-10),
+    ("Laplace", 16, 4, 1, -1, 1e-10),
+    ("Laplace", 16, 4, 2, 2, 1e-10),
+    ("Laplace", 32, 4, 2, -1, 1e-10),   # reference testSuite/integration_tests/threeD1.xml
+    ("Laplace", 32, 8, 1, -1, 1e-10),
+    ("Stokes-C", 8, 4, 0, -1, 1e-9),
+    ("Stokes-C", 16, 8, 0, -1, 1e-8),
+]
+
+
+@pytest.mark.parametrize("eq,n,sx,levels,cx,tol", CASES)
+def test_apply_inverse_matches_oracle(gpu_lib, eq, n, sx, levels, cx, tol):
+    A, tv = problem(eq, n)
+    P = product_prec(A, tv, xml_params(eq, n, sx, levels, cx), gpu_lib)
+    O = oracle_prec(A, tv, eq, n, sx, levels, cx)
+    assert [s[1] for s in P.level_sizes()][: len(O.level_sizes())] == [s[1] for s in O.level_sizes()]
+    rng = np.random.default_rng(42)
+    for _ in range(2):
+        b = rng.uniform(-1, 1, A.shape[0])
+        assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < tol
+    # multivector (column-major, ld = n) and repeatability
+    B = rng.uniform(-1, 1, (A.shape[0], 3))
+    X = P.ApplyInverse(B)
+    for k in range(3):
+        assert rel_diff(X[:, k], O.apply_inverse(B[:, k])) < tol
+    assert np.array_equal(P.ApplyInverse(B[:, 0]), X[:, 0])  # bitwise reproducible
+    assert P.NumApplyInverse() >= 4 and P.NumCompute() == 1
+
+
+def test_device_resident_vectors(gpu_lib):
+    import torch
+    A, tv = problem("Laplace", 16)
+    P = product_prec(A, tv, xml_params("Laplace", 16, 4, 1), gpu_lib)
+    b = np.random.default_rng(1).uniform(-1, 1, A.shape[0])
+    x_host = P.ApplyInverse(b)
+    x_dev = P.ApplyInverse(torch.from_numpy(b).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(x_dev.cpu().numpy(), x_host)
+    y = P.MatVec(torch.from_numpy(b).cuda()).cpu().numpy()
+    assert rel_diff(y, A @ b) < 1e-14
+
+
+def test_exact_inverse_levels0(gpu_lib):
+    """levels=0 => ApplyInverse(K x) = x (reference testSuite/unit_tests/HYMLS_Preconditioner.cpp:247-276)."""
+    A, tv = problem("Laplace", 16)
+    P = product_prec(A, tv, xml_params("Laplace", 16, 4, 0), gpu_lib)
+    x = np.random.default_rng(2).uniform(-1, 1, A.shape[0])
+    assert np.abs(P.ApplyInverse(A @ x) - x).max() < 1e-10
+
+
+def test_krylov_iteration_count_matches_oracle(gpu_lib):
+    """threeD1.xml: 3D Laplace 32^3, sx=4, levels=2, CG tol 1e-10: <= 35 iterations in the
+    reference; GPU path and oracle must need the same number."""
+    A, tv = problem("Laplace", 32)
+    P = product_prec(A, tv, xml_params("Laplace", 32, 4, 2), gpu_lib)
+    O = oracle_prec(A, tv, "Laplace", 32, 4, 2)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, A.shape[0]); b = A @ x
+    x0 = rng.uniform(-1, 1, A.shape[0])
+    _, its_o, res_o = krylov.pcg(lambda v: A @ v, b, O.apply_inverse, tol=1e-10, maxit=100, x0=x0)
+    _, its_p, res_p = krylov.pcg(lambda v: A @ v, b, P.ApplyInverse, tol=1e-10, maxit=100, x0=x0)
+    assert its_p == its_o and its_p <= 35 and res_p <= 1e-9
+
+
+def test_set_matrix_recompute(gpu_lib):
+    """SetMatrix with the same pattern + Compute reuses the symbolic work (reference
+    src/HYMLS_Preconditioner.hpp:244-254, testSuite/unit_tests/HYMLS_Preconditioner.cpp:106-124)."""
+    A, tv = problem("Laplace", 16)
+    P = product_prec(A, tv, xml_params("Laplace", 16, 4, 1), gpu_lib)
+    A2 = A * 2.0
+    P.SetMatrix(A2)
+    assert not P.IsComputed()
+    P.Compute()
+    O = oracle_prec(A2, tv, "Laplace", 16, 4, 1)
+    b = np.random.default_rng(4).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-10
+    assert P.NumInitialize() == 1 and P.NumCompute() == 2
+
+
+def test_errors(gpu_lib):
+    import hymls_amd
+    A, tv = problem("Laplace", 8)
+    P = hymls_amd.Preconditioner(A, xml_params("Laplace", 8, 4, 0), testVector=tv, lib=gpu_lib)
+    with pytest.raises(hymls_amd.HymlsError) as e:
+        P.ApplyInverse(np.ones(A.shape[0]))
+    assert e.value.code == -1  # "The preconditioner has not yet been computed."
+    assert P.Apply(None, None) == -1 and P.SetUseTranspose(True) == -1 and P.Condest() == -1.0
+    # 3D Stokes-C with the Cartesian partitioner: singular pressure-tube blocks are reported
+    A, tv = problem("Stokes-C", 8)
+    P = hymls_amd.Preconditioner(A, xml_params("Stokes-C", 8, 4, 1), testVector=tv, lib=gpu_lib)
+    with pytest.raises(hymls_amd.HymlsError) as e:
+        P.Compute()
+    assert e.value.code == -4

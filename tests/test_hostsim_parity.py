@@ -1,0 +1,81 @@
+"""-m "not gpu": host logic (partition, ordering, assembly tree, index plans, recursion) driven
+end-to-end through the C ABI with the TEST-ONLY device simulator (tests/hostsim), compared with
+the oracle.  This validates the integer plans the GPU kernels execute; the kernels themselves
+are covered by the -m gpu tests."""
+import numpy as np
+import pytest
+
+from common import problem, xml_params, oracle_prec, product_prec, rel_diff
+from oracle.partition import Params, HierarchicalMap
+
+CASES = [
+    ("Laplace", 8, 4, 0, -1, 1e-12),
+    ("Laplace", 8, 4, 1, -1, 1e-12),
+    ("Laplace", 16, 4, 2, 2, 1e-12),
+    ("Laplace", 16, 8, 1, -1, 1e-12),
+    ("Stokes-C", 8, 4, 0, -1, 1e-10),
+]
+
+
+@pytest.mark.parametrize("eq,n,sx,levels,cx,tol", CASES)
+def test_apply_inverse_matches_oracle(hostsim_lib, eq, n, sx, levels, cx, tol):
+    A, tv = problem(eq, n)
+    P = product_prec(A, tv, xml_params(eq, n, sx, levels, cx), hostsim_lib)
+    O = oracle_prec(A, tv, eq, n, sx, levels, cx)
+    assert [s[1] for s in P.level_sizes()][: len(O.level_sizes())] == [s[1] for s in O.level_sizes()]
+    b = np.random.default_rng(7).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < tol
+
+
+@pytest.mark.parametrize("eq,n,sx", [("Laplace", 16, 4), ("Stokes-C", 16, 4), ("Stokes-C", 16, 8)])
+def test_partition_matches_oracle(hostsim_lib, eq, n, sx):
+    """group lists of the C++ partitioner == oracle restatement (which is pinned by the
+    reference's unit-test formulas in test_oracle_pins.py)."""
+    A, tv = problem(eq, n)
+    import hymls_amd
+    P = hymls_amd.Preconditioner(A, xml_params(eq, n, sx, 0), testVector=tv, lib=hostsim_lib)
+    P.Initialize()
+    hm = HierarchicalMap(Params(nx=n, ny=n, nz=n, sx=sx, levels=0, equations=eq).finalize())
+    assert P.level_sizes()[0][3] == hm.nsd
+    for sd in range(hm.nsd):
+        assert np.array_equal(P.interior(0, sd), hm.interior[sd])
+        groups = P.separator_groups(0, sd)
+        assert len(groups) == len(hm.groups[sd])
+        for gi, (typ, owned, nodes) in enumerate(groups):
+            assert typ == hm.groups[sd][gi][0]
+            assert np.array_equal(nodes, hm.groups[sd][gi][1])
+            assert owned == (gi in hm.owned[sd])
+
+
+def test_nonuniform_grid_and_ragged_subdomains(hostsim_lib):
+    """nx not a multiple of sx (ragged last subdomains), anisotropic grid."""
+    import hymls_amd
+    from oracle import galeri
+    from oracle.hymls import Preconditioner as OraclePrec
+    nx, ny, nz, sx = 10, 8, 6, 4
+    A = galeri.laplace3d(nx, ny, nz)
+    tv = galeri.create_testvector(A)
+    prm = {"Problem": {"Equations": "Laplace", "Dimension": 3, "nx": nx, "ny": ny, "nz": nz},
+           "Preconditioner": {"Separator Length": sx, "Number of Levels": 1}}
+    P = product_prec(A, tv, prm, hostsim_lib)
+    O = OraclePrec(A, Params(nx=nx, ny=ny, nz=nz, sx=sx, levels=1, equations="Laplace").finalize(), testvector=tv).compute()
+    b = np.random.default_rng(8).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-12
+
+
+def test_lifecycle_and_errors(hostsim_lib):
+    import hymls_amd
+    A, tv = problem("Laplace", 8)
+    P = hymls_amd.Preconditioner(A, xml_params("Laplace", 8, 4, 0), testVector=tv, lib=hostsim_lib)
+    with pytest.raises(hymls_amd.HymlsError) as e:
+        P.ApplyInverse(np.ones(A.shape[0]))
+    assert e.value.code == -1
+    assert P.Compute() == 0  # auto-initialises (reference Preconditioner.cpp:403-409)
+    assert P.IsInitialized() and P.IsComputed() and P.NumInitialize() == 1
+    x = np.random.default_rng(9).uniform(-1, 1, A.shape[0])
+    assert np.abs(P.ApplyInverse(A @ x) - x).max() < 1e-10  # levels=0 is exact
+    A3, tv3 = problem("Stokes-C", 8)
+    P = hymls_amd.Preconditioner(A3, xml_params("Stokes-C", 8, 4, 1), testVector=tv3, lib=hostsim_lib)
+    with pytest.raises(hymls_amd.HymlsError) as e:
+        P.Compute()
+    assert e.value.code == -4

@@ -36,6 +36,7 @@ class Params:
     link_retained: bool = True    # BasePartitioner.cpp:139
     fix_gids: list = field(default_factory=list)
     equations: str = "Laplace"
+    partitioner: str = "Cartesian"  # or "Skew Cartesian"
 
     def finalize(self):
         """BasePartitioner::SetParameters defaults (BasePartitioner.cpp:70-252)."""
@@ -204,7 +205,11 @@ class HierarchicalMap:
         """present: boolean mask over all N gids that exist in the level's base map
         (None = all)."""
         self.p = params
-        part = CartesianPartitioner(params)
+        if params.partitioner == "Skew Cartesian":
+            from .skew import SkewPartitioner
+            part = SkewPartitioner(params)
+        else:
+            part = CartesianPartitioner(params)
         self.part = part
         nsd = part.num_subdomains()
         self.interior, self.groups, self.owned, self.linked = [], [], [], []

@@ -41,6 +41,42 @@ def test_apply_inverse_matches_oracle(gpu_lib, eq, n, sx, levels, cx, tol):
     assert P.NumApplyInverse() >= 4 and P.NumCompute() == 1
 
 
+SKEW = [
+    (8, 4, 0, -1, {}, 1e-9),
+    (16, 8, 1, -1, {}, 1e-8),
+    (16, 4, 2, 2, {"Eliminate Velocities Together": False}, 1e-8),   # stokes2_3D.xml shape
+    (32, 8, 1, -1, {}, 1e-8),                                        # stokes1_3D.xml shape (32^3)
+]
+
+
+@pytest.mark.parametrize("n,sx,levels,cx,extra,tol", SKEW)
+def test_stokes_skew_matches_oracle(gpu_lib, n, sx, levels, cx, extra, tol):
+    A, tv = problem("Stokes-C", n)
+    P = product_prec(A, tv, xml_params("Stokes-C", n, sx, levels, cx, "Skew Cartesian", extra=extra), gpu_lib)
+    O = oracle_prec(A, tv, "Stokes-C", n, sx, levels, cx, partitioner="Skew Cartesian",
+                    link_velocities=extra.get("Eliminate Velocities Together", True))
+    assert [s[1] for s in P.level_sizes()] == [s[1] for s in O.level_sizes()]
+    rng = np.random.default_rng(5)
+    b = rng.uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < tol
+    # divergence-free property (reference testSuite/integration_tests/integration_tests.cpp:453-484)
+    b0 = b.copy(); b0[3::4] = 0.0
+    assert np.abs((A @ P.ApplyInverse(b0))[3::4]).max() <= 1e-8 * np.abs(b0).max() * A.shape[0]
+
+
+def test_stokes_gmres_iterations_match_oracle(gpu_lib):
+    """stokes1_3D.xml shape at 16^3: right-preconditioned GMRES, tol 1e-8; reference target <= 130."""
+    n, sx = 16, 8
+    A, tv = problem("Stokes-C", n)
+    P = product_prec(A, tv, xml_params("Stokes-C", n, sx, 1, partitioner="Skew Cartesian"), gpu_lib)
+    O = oracle_prec(A, tv, "Stokes-C", n, sx, 1, partitioner="Skew Cartesian")
+    rng = np.random.default_rng(6)
+    x = rng.uniform(-1, 1, A.shape[0]); b = A @ x
+    _, its_o, res_o = krylov.gmres(lambda v: A @ v, b, O.apply_inverse, tol=1e-8, maxit=200)
+    _, its_p, res_p = krylov.gmres(lambda v: A @ v, b, P.ApplyInverse, tol=1e-8, maxit=200)
+    assert abs(its_p - its_o) <= 1 and its_p <= 130 and res_p < 1e-7
+
+
 def test_device_resident_vectors(gpu_lib):
     import torch
     A, tv = problem("Laplace", 16)

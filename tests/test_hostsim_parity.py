@@ -47,6 +47,45 @@ def test_partition_matches_oracle(hostsim_lib, eq, n, sx):
             assert owned == (gi in hm.owned[sd])
 
 
+SKEW = [
+    # n, sx, levels, cx, extra, tol  (reference testSuite/integration_tests/stokes{0,1,2}_3D.xml shapes)
+    (8, 4, 0, -1, {}, 1e-10),
+    (8, 4, 1, -1, {}, 1e-10),
+    (16, 8, 1, -1, {}, 1e-9),
+    (16, 4, 2, 2, {"Eliminate Velocities Together": False}, 1e-9),
+]
+
+
+@pytest.mark.parametrize("n,sx,levels,cx,extra,tol", SKEW)
+def test_stokes_skew_matches_oracle(hostsim_lib, n, sx, levels, cx, extra, tol):
+    A, tv = problem("Stokes-C", n)
+    P = product_prec(A, tv, xml_params("Stokes-C", n, sx, levels, cx, "Skew Cartesian", extra=extra), hostsim_lib)
+    O = oracle_prec(A, tv, "Stokes-C", n, sx, levels, cx, partitioner="Skew Cartesian",
+                    link_velocities=extra.get("Eliminate Velocities Together", True))
+    assert [s[1] for s in P.level_sizes()] == [s[1] for s in O.level_sizes()]
+    b = np.random.default_rng(11).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < tol
+
+
+@pytest.mark.parametrize("n,sx,nz", [(8, 4, 8), (16, 8, 16), (12, 2, 12), (16, 4, 8)])
+def test_skew_partition_matches_oracle(hostsim_lib, n, sx, nz):
+    import hymls_amd
+    A, tv = problem("Stokes-C", n, nz)
+    P = hymls_amd.Preconditioner(A, xml_params("Stokes-C", n, sx, 0, partitioner="Skew Cartesian", nz=nz),
+                                 testVector=tv, lib=hostsim_lib)
+    P.Initialize()
+    hm = HierarchicalMap(Params(nx=n, ny=n, nz=nz, sx=sx, levels=0, equations="Stokes-C",
+                                partitioner="Skew Cartesian").finalize())
+    assert P.level_sizes()[0][3] == hm.nsd
+    for sd in range(hm.nsd):
+        assert np.array_equal(P.interior(0, sd), hm.interior[sd])
+        groups = P.separator_groups(0, sd)
+        assert len(groups) == len(hm.groups[sd])
+        for gi, (typ, owned, nodes) in enumerate(groups):
+            assert typ == hm.groups[sd][gi][0] and np.array_equal(nodes, hm.groups[sd][gi][1])
+            assert owned == (gi in hm.owned[sd])
+
+
 def test_nonuniform_grid_and_ragged_subdomains(hostsim_lib):
     """nx not a multiple of sx (ragged last subdomains), anisotropic grid."""
     import hymls_amd

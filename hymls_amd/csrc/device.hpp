@@ -92,6 +92,17 @@ void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const
 void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x);
 void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x);
 
+// ---- fused interior solve: one workgroup per subdomain walks its whole assembly tree
+// (forward then backward) with the solution vector and all contribution vectors in LDS;
+// one launch covers every subdomain of every pattern class of a level.
+struct FusedSub {
+  const double* fac;   // factor slab of this subdomain
+  int32_t xoff;        // offset of its interior block in the level vector
+  int32_t cls;         // index into the PlanD table
+};
+constexpr int FUSED_MAX_ROWS = 1024;   // max w + ri of a front handled by the fused kernel
+void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, double* x);
+
 // ---- separator-side kernels
 // Householder per owned group on a level separator vector: x <- 2 w (w.x) - x
 // gptr[ng+1] offsets into the separator vector; w = 0 rows mean "x <- -x" (reference quirk)

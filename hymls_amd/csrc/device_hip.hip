@@ -503,6 +503,155 @@ void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32
   }
 }
 
+// ------------------------------------------------------------------ fused interior solve
+// One workgroup per subdomain.  LDS: X[nI] solution, C[contrib_size] contribution vectors,
+// R[FUSED_MAX_ROWS] cross-thread reduction scratch.  Fronts are walked in elimination order;
+// a front's panel ((w+ri) x w, column-major) is read with rows on consecutive lanes, the k range
+// split over KG = 256/RT thread groups so that small fronts still keep many loads in flight.
+// Children push their contribution straight into the parent's rows (X for its pivot columns,
+// C for its update rows): fronts run one after the other inside the workgroup, so there are no
+// write conflicts and the result is bitwise reproducible.
+__global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
+                                                         double* __restrict__ x) {
+  extern __shared__ double lds[];
+  const FusedSub S = subs[blockIdx.x];
+  const PlanD P = plans[S.cls];
+  double* X = lds;
+  double* C = lds + P.nI;
+  double* R = C + P.contrib_size;
+  const int tid = threadIdx.x;
+  double* xg = x + S.xoff;
+  for (int i = tid; i < P.nI; i += 256) X[i] = xg[i];
+  for (int i = tid; i < P.contrib_size; i += 256) C[i] = 0.0;
+  __syncthreads();
+  const double* __restrict__ fac = S.fac;
+  // ---------------- forward
+  for (int s = 0; s < P.nfronts; s++) {
+    const FrontD F = P.fronts[s];
+    const int w = F.w, ri = F.ri, rows = w + ri;
+    const int64_t ld = rows;
+    const double* __restrict__ Lp = fac + F.lp_off;
+    int RT = 64;
+    while (RT < rows && RT < 256) RT <<= 1;
+    const int KG = 256 / RT;
+    const int rt = tid % RT, kg = tid / RT;
+    const double* Xs = X + F.c0;
+    if (KG == 1) {
+      // rows on threads (up to 4 rows per thread), whole k range per thread
+      double part[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int i = tid + rr * 256;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (i < rows) {
+          const int kmax = i < w ? i : w;
+          const double* p = Lp + i;
+          int k = 0;
+          for (; k + 3 < kmax; k += 4) {
+            a0 += p[ld * k] * Xs[k];
+            a1 += p[ld * (k + 1)] * Xs[k + 1];
+            a2 += p[ld * (k + 2)] * Xs[k + 2];
+            a3 += p[ld * (k + 3)] * Xs[k + 3];
+          }
+          for (; k < kmax; k++) a0 += p[ld * k] * Xs[k];
+        }
+        part[rr] = (a0 + a1) + (a2 + a3);
+      }
+      __syncthreads();   // every read of X[c0..c0+w) is done
+      const int32_t* rel = P.rel + F.rel_off;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int i = tid + rr * 256;
+        if (i < w) X[F.c0 + i] += part[rr];
+        else if (i < rows) {
+          const double c = C[F.c_off + i - w] - part[rr];
+          const FrontD Pa = P.fronts[F.parent];
+          const int pos = rel[i - w];
+          if (pos < Pa.w) X[Pa.c0 + pos] += c; else C[Pa.c_off + pos - Pa.w] += c;
+        }
+      }
+      __syncthreads();
+    } else {
+      // rows <= 128: RT row-threads x KG k-groups, partial sums combined through LDS
+      double a0 = 0.0, a1 = 0.0;
+      if (rt < rows) {
+        const int kmax = rt < w ? rt : w;
+        const double* p = Lp + rt;
+        int k = kg;
+        for (; k + KG < kmax; k += 2 * KG) {
+          a0 += p[ld * k] * Xs[k];
+          a1 += p[ld * (k + KG)] * Xs[k + KG];
+        }
+        if (k < kmax) a0 += p[ld * k] * Xs[k];
+      }
+      R[kg * RT + rt] = a0 + a1;
+      __syncthreads();
+      const int32_t* rel = P.rel + F.rel_off;
+      if (tid < rows) {
+        double sum = 0.0;
+        for (int g = 0; g < KG; g++) sum += R[g * RT + tid];
+        if (tid < w) X[F.c0 + tid] += sum;
+        else {
+          const double c = C[F.c_off + tid - w] - sum;
+          const FrontD Pa = P.fronts[F.parent];
+          const int pos = rel[tid - w];
+          if (pos < Pa.w) X[Pa.c0 + pos] += c; else C[Pa.c_off + pos - Pa.w] += c;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---------------- backward
+  for (int s = P.nfronts - 1; s >= 0; s--) {
+    const FrontD F = P.fronts[s];
+    const int w = F.w, ri = F.ri;
+    const int64_t ld = w + ri;
+    const double* __restrict__ Lp = fac + F.lp_off;
+    const double* __restrict__ Q = fac + F.q_off;
+    const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+    int RT = 64;
+    while (RT < w && RT < 256) RT <<= 1;
+    const int KG = 256 / RT;
+    const int rt = tid % RT, kg = tid / RT;
+    const double* Xs = X + F.c0;
+    double a0 = 0.0, a1 = 0.0;
+    if (rt < w) {
+      const double* p = Lp + rt;
+      // upper triangle of the pivot block: k >= rt
+      int k = rt + kg;
+      for (; k + KG < w; k += 2 * KG) {
+        a0 += p[ld * k] * Xs[k];
+        a1 += p[ld * (k + KG)] * Xs[k + KG];
+      }
+      if (k < w) a0 += p[ld * k] * Xs[k];
+      const double* q = Q + rt;
+      k = kg;
+      for (; k + KG < ri; k += 2 * KG) {
+        a0 -= q[(int64_t)w * k] * X[idx[k]];
+        a1 -= q[(int64_t)w * (k + KG)] * X[idx[k + KG]];
+      }
+      if (k < ri) a0 -= q[(int64_t)w * k] * X[idx[k]];
+    }
+    R[kg * RT + rt] = a0 + a1;
+    __syncthreads();
+    if (tid < w) {
+      double sum = 0.0;
+      for (int g = 0; g < KG; g++) sum += R[g * RT + tid];
+      X[F.c0 + tid] = sum;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < P.nI; i += 256) xg[i] = X[i];
+}
+
+void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, double* x) {
+  if (nsub <= 0) return;
+  const size_t shm = (size_t)lds_doubles * sizeof(double);
+  if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_interior_fused, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x);
+  launch_check();
+}
+
 // ------------------------------------------------------------------ separator-side kernels
 // one wave per group: dot product by shuffle reduction, then the axpy
 __global__ void __launch_bounds__(256) k_ot(int32_t ng, const int32_t* __restrict__ gptr, const double* __restrict__ w, double* __restrict__ x) {

@@ -217,6 +217,7 @@ LevelSolver::~LevelSolver() {
                   d_a12_src_, d_a21_row_, d_a21_col_, d_a21_src_, d_a12_val_, d_a21_val_, d_gptr_, d_otw_,
                   d_vs_, d_red_pull_ptr_, d_red_pull_idx_, d_red_val_, d_ext_, d_vrhs_, d_vsol_, d_yb_, d_flag_};
   for (void* q : ptrs) dev::free(q);
+  dev::free(d_fsubs_); dev::free(d_fplans_);
   for (auto& b : blocks_) { dev::free(b.d_binv); dev::free(b.d_ids); dev::free(b.d_pull_ptr); dev::free(b.d_pull_base); }
 }
 
@@ -558,6 +559,25 @@ void LevelSolver::build_schur_setup() {
     C.d_tvloc = dev::upload(C.tvloc);
     C.lu.upload(SCRATCH_BUDGET, true);
   }
+  // ---- tables of the fused interior solve (classes whose vectors fit in LDS)
+  constexpr int32_t LDS_CAP = 12288;  // doubles (96 KiB)
+  std::vector<dev::PlanD> plans;
+  std::vector<dev::FusedSub> subs;
+  cls_fused_.assign(cls_.size(), 0);
+  fused_lds_ = 0;
+  for (size_t c = 0; c < cls_.size(); c++) {
+    Cls& C = *cls_[c];
+    plans.push_back(C.lu.dplan);
+    const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + dev::FUSED_MAX_ROWS;
+    if (C.lu.plan.max_solve_rows > dev::FUSED_MAX_ROWS || need > LDS_CAP || C.lu.plan.nI == 0) continue;
+    cls_fused_[c] = 1;
+    fused_lds_ = std::max(fused_lds_, need);
+    for (size_t b = 0; b < C.lu.members.size(); b++)
+      subs.push_back(dev::FusedSub{C.lu.batch.factor + (int64_t)b * C.lu.plan.factor_size, C.lu.h_xoff[b], (int32_t)c});
+  }
+  n_fsubs_ = (int32_t)subs.size();
+  d_fplans_ = dev::upload(plans);
+  d_fsubs_ = dev::upload(subs);
 }
 
 void LevelSolver::set_values(const dvec& val) {
@@ -643,7 +663,9 @@ void LevelSolver::compute() {
 }
 
 void LevelSolver::interior_solve(double* x1) {
-  for (auto& cp : cls_) cp->lu.solve(x1);
+  if (n_fsubs_ > 0) dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, x1);
+  for (size_t c = 0; c < cls_.size(); c++)
+    if (!cls_fused_[c]) cls_[c]->lu.solve(x1);
 }
 
 void LevelSolver::schur_apply(double* rhs2, double* x2) {

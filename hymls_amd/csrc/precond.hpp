@@ -109,6 +109,11 @@ class LevelSolver : public Operator {
   ivec in_perm_;             // internal index -> level row
   ivec sd_xoff_, sd_cls_, sd_bidx_;
   std::vector<std::unique_ptr<Cls>> cls_;
+  // fused interior solve tables
+  dev::FusedSub* d_fsubs_ = nullptr;
+  dev::PlanD* d_fplans_ = nullptr;
+  int32_t n_fsubs_ = 0, fused_lds_ = 0;
+  std::vector<char> cls_fused_;
   // device
   double* d_kval_ = nullptr;
   int32_t *d_krow_ = nullptr, *d_kcol_ = nullptr;

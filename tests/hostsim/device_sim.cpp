@@ -179,6 +179,49 @@ void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32
     }
 }
 
+void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t, double* x) {
+  std::vector<double> C, acc;
+  for (int b = 0; b < nsub; b++) {
+    const PlanD& P = plans[subs[b].cls];
+    double* xb = x + subs[b].xoff;
+    const double* fac = subs[b].fac;
+    C.assign(std::max(P.contrib_size, 1), 0.0);
+    for (int s = 0; s < P.nfronts; s++) {  // forward, children push into their parent
+      const FrontD& F = P.fronts[s];
+      const int w = F.w, ri = F.ri, ld = w + ri;
+      const double* Lp = fac + F.lp_off;
+      acc.assign(ld, 0.0);
+      for (int i = 0; i < ld; i++) {
+        double a = 0;
+        const int kmax = i < w ? i : w;
+        for (int k = 0; k < kmax; k++) a += Lp[i + (int64_t)ld * k] * xb[F.c0 + k];
+        acc[i] = a;
+      }
+      for (int i = 0; i < w; i++) xb[F.c0 + i] += acc[i];
+      const int32_t* rel = P.rel + F.rel_off;
+      for (int i = 0; i < ri; i++) {
+        const double c = C[F.c_off + i] - acc[w + i];
+        const FrontD& Pa = P.fronts[F.parent];
+        if (rel[i] < Pa.w) xb[Pa.c0 + rel[i]] += c; else C[Pa.c_off + rel[i] - Pa.w] += c;
+      }
+    }
+    for (int s = P.nfronts - 1; s >= 0; s--) {  // backward
+      const FrontD& F = P.fronts[s];
+      const int w = F.w, ri = F.ri, ld = w + ri;
+      const double* Lp = fac + F.lp_off;
+      const double* Q = fac + F.q_off;
+      acc.assign(w, 0.0);
+      for (int i = 0; i < w; i++) {
+        double a = 0;
+        for (int k = i; k < w; k++) a += Lp[i + (int64_t)ld * k] * xb[F.c0 + k];
+        for (int k = 0; k < ri; k++) a -= Q[i + (int64_t)w * k] * xb[P.fidx[F.idx_off + w + k]];
+        acc[i] = a;
+      }
+      for (int i = 0; i < w; i++) xb[F.c0 + i] = acc[i];
+    }
+  }
+}
+
 void ot_apply(int32_t ng, const int32_t* gptr, const double* w, double* x) {
   for (int g = 0; g < ng; g++) {
     double s = 0;

@@ -3,7 +3,7 @@ import sys, time, json
 import numpy as np, torch
 import hymls_amd
 eq, n, sx, levels = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-part = sys.argv[5] if len(sys.argv) > 5 else "Cartesian"
+part = (sys.argv[5] if len(sys.argv) > 5 else "Cartesian").replace("_", " ")
 t = time.time(); rp, ci, va = hymls_amd.generate_matrix(eq, n, n, n); tv = hymls_amd.generate_testvector(rp, ci, va); tg = time.time() - t
 prm = {"Problem": {"Equations": eq, "Dimension": 3, "nx": n, "ny": n, "nz": n},
        "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": part}}

@@ -65,6 +65,10 @@ struct BatchD {
   double* sblock;        // [chunk][nS*nS]          separator (Schur) block, col-major
   double* contrib;       // [nb][contrib_size]      solve scratch
   int32_t* flag;         // device int: set != 0 on zero / non-finite pivot
+  double* tmp;           // [chunk][2*max_w*max_w] dense copies of the pivot-block inverses (big fronts)
+  int64_t tmp_stride;
+  double* swork;         // [nb][swork_stride] solve workspace of the big fronts
+  int64_t swork_stride;
 };
 
 // ---- vector kernels
@@ -87,6 +91,12 @@ void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t 
                   int32_t b0, int32_t nbc, const double* kval);
 // separator block: S = weighted A22 entries (call before the tree), per batch member
 void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const double* kval);
+
+// one big front, spread over many workgroups (kids: host copies of its children)
+void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD* kids, int32_t nkids,
+                      int32_t b0, int32_t nbc, const double* kval);
+void solve_fwd_big(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD* kids, int32_t nkids, double* x);
+void solve_bwd_big(const PlanD& P, const BatchD& B, const FrontD& F, double* x);
 
 // ---- solves with the factor panels; x is the level vector (interior part), in place
 void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x);

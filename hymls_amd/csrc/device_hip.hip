@@ -405,6 +405,358 @@ void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const
   }
 }
 
+// ------------------------------------------------------------------ big fronts (many workgroups per front)
+// The same algebra as k_factor_level, cut into grid-wide steps: assemble, LU + inverses of the
+// pivot block (one workgroup), panel products, Schur update on the FP64 matrix cores.
+__global__ void k_big_zero(double* __restrict__ A, int64_t mm, int64_t stride) {
+  double* p = A + (int64_t)blockIdx.y * stride;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < mm; t += (int64_t)gridDim.x * blockDim.x) p[t] = 0.0;
+}
+__global__ void k_big_entries(PlanD P, BatchD B, FrontD F, int32_t b0, const double* __restrict__ kval) {
+  const int slot = blockIdx.y;
+  double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
+  const int32_t* src = B.src + (int64_t)(b0 + slot) * P.nent;
+  for (int e = F.ent_begin + blockIdx.x * blockDim.x + threadIdx.x; e < F.ent_end; e += gridDim.x * blockDim.x)
+    A[P.ent_pos[e]] += P.ent_w[e] * kval[src[P.ent_id[e]]];
+}
+__global__ void k_big_extend_add(PlanD P, BatchD B, FrontD F, FrontD Cf) {
+  const int slot = blockIdx.y;
+  double* sc = B.scratch + (int64_t)slot * P.scratch_size;
+  double* A = sc + F.f_off;
+  const double* Ac = sc + Cf.f_off;
+  const int m = F.w + F.ri + F.rs, mc = Cf.w + Cf.ri + Cf.rs, rc = Cf.ri + Cf.rs;
+  const int32_t* rel = P.rel + Cf.rel_off;
+  const int64_t tot = (int64_t)rc * rc;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)(t % rc), bb = (int)(t / rc);
+    A[rel[a] + (int64_t)m * rel[bb]] += Ac[(Cf.w + a) + (int64_t)mc * (Cf.w + bb)];
+  }
+}
+// LU of the pivot block + packed inverses into the factor slab + dense copies (Linv | Uinv) in tmp
+__global__ void __launch_bounds__(FT) k_big_pivot(PlanD P, BatchD B, FrontD F, int32_t b0) {
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, slot = blockIdx.x, b = b0 + slot;
+  const int w = F.w, m = F.w + F.ri + F.rs;
+  double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  for (int k = 0; k < w; k++) {
+    const double piv = A[k + (int64_t)m * k];
+    if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
+    const double ip = 1.0 / piv;
+    __syncthreads();
+    for (int i = k + 1 + tid; i < w; i += FT) A[i + (int64_t)m * k] *= ip;
+    __syncthreads();
+    const int rem = w - k - 1;
+    for (int t = tid; t < rem * rem; t += FT) {
+      const int i = k + 1 + t % rem, j = k + 1 + t / rem;
+      A[i + (int64_t)m * j] -= A[i + (int64_t)m * k] * A[k + (int64_t)m * j];
+    }
+    __syncthreads();
+  }
+  if (s_bad && tid == 0) atomicExch(B.flag, 1);
+  double* Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off;
+  const int64_t ld = F.w + F.ri;
+  double* Lf = B.tmp + (int64_t)slot * B.tmp_stride;   // dense L11^{-1} (w x w)
+  double* Uf = Lf + (int64_t)w * w;                    // dense U11^{-1}
+  for (int t = tid; t < w; t += FT) {
+    for (int i = 0; i < t; i++) Lf[i + (int64_t)w * t] = 0.0;
+    Lf[t + (int64_t)w * t] = 1.0;
+    for (int i = t + 1; i < w; i++) {
+      double s = A[i + (int64_t)m * t];
+      for (int j = t + 1; j < i; j++) s += A[i + (int64_t)m * j] * Lp[j + ld * t];
+      Lp[i + ld * t] = -s;
+      Lf[i + (int64_t)w * t] = -s;
+    }
+    const double d = 1.0 / A[t + (int64_t)m * t];
+    Lp[t + ld * t] = d;
+    Uf[t + (int64_t)w * t] = d;
+    for (int i = t + 1; i < w; i++) Uf[i + (int64_t)w * t] = 0.0;
+    for (int i = t - 1; i >= 0; i--) {
+      double s = 0.0;
+      for (int j = i + 1; j <= t; j++) s += A[i + (int64_t)m * j] * Lp[j + ld * t];
+      const double v = -s / A[i + (int64_t)m * i];
+      Lp[i + ld * t] = v;
+      Uf[i + (int64_t)w * t] = v;
+    }
+  }
+}
+// U12 = L11^{-1} F12 in place: one workgroup per block of 8 columns
+__global__ void __launch_bounds__(256) k_big_trmm_u(PlanD P, BatchD B, FrontD F) {
+  extern __shared__ double st[];
+  const int slot = blockIdx.y, tid = threadIdx.x;
+  const int w = F.w, m = F.w + F.ri + F.rs, r = F.ri + F.rs;
+  double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
+  const double* Lf = B.tmp + (int64_t)slot * B.tmp_stride;
+  const int j0 = blockIdx.x * 8, nc = min(8, r - j0);
+  for (int t = tid; t < w * nc; t += 256) st[t] = A[(t % w) + (int64_t)m * (w + j0 + t / w)];
+  __syncthreads();
+  for (int t = tid; t < w * nc; t += 256) {
+    const int i = t % w, j = t / w;
+    double s = st[i + w * j];
+    for (int k = 0; k < i; k++) s += Lf[i + (int64_t)w * k] * st[k + w * j];
+    A[i + (int64_t)m * (w + j0 + j)] = s;
+  }
+}
+// L21 = F21 U11^{-1} in place: one workgroup per block of 8 rows
+__global__ void __launch_bounds__(256) k_big_trmm_l(PlanD P, BatchD B, FrontD F) {
+  extern __shared__ double st[];
+  const int slot = blockIdx.y, tid = threadIdx.x;
+  const int w = F.w, m = F.w + F.ri + F.rs, r = F.ri + F.rs;
+  double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
+  const double* Uf = B.tmp + (int64_t)slot * B.tmp_stride + (int64_t)w * w;
+  const int i0 = blockIdx.x * 8, nr = min(8, r - i0);
+  for (int t = tid; t < nr * w; t += 256) st[t] = A[(w + i0 + t % nr) + (int64_t)m * (t / nr)];
+  __syncthreads();
+  for (int t = tid; t < nr * w; t += 256) {
+    const int i = t % nr, j = t / nr;
+    double s = 0.0;
+    for (int k = 0; k <= j; k++) s += st[i + nr * k] * Uf[k + (int64_t)w * j];
+    A[(w + i0 + i) + (int64_t)m * j] = s;
+  }
+}
+
+// C (MxN) = C - A B  or  C = A B on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), column-major.
+// 64x64 tile per workgroup, each of the 4 waves owns a 32x32 quadrant = 2x2 MFMA tiles; A and B
+// slabs of 16 in K are staged through LDS (k-major so that every MFMA operand read is conflict
+// free).  Lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; result register r
+// holds D[row = (l >> 4) + 4 r][col = l & 15] (f64 layout, cdna_hip_programming.md section 3).
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <bool SUBTRACT>
+__global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_t ldc, int64_t strideC,
+                                                   const double* __restrict__ A, int64_t lda, int64_t strideA,
+                                                   const double* __restrict__ Bm, int64_t ldb, int64_t strideB,
+                                                   int M, int N, int K) {
+  __shared__ double As[16 * 64];
+  __shared__ double Bs[16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  const int tm = blockIdx.x * 64, tn = blockIdx.y * 64;
+  C += (int64_t)blockIdx.z * strideC; A += (int64_t)blockIdx.z * strideA; Bm += (int64_t)blockIdx.z * strideB;
+  d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    __syncthreads();
+    for (int t = tid; t < 16 * 64; t += 256) {
+      const int r = t & 63, kk = t >> 6;
+      const int gm = tm + r, gk = k0 + kk;
+      As[kk * 64 + r] = (gm < M && gk < K) ? A[gm + lda * gk] : 0.0;
+    }
+    for (int t = tid; t < 16 * 64; t += 256) {
+      const int kk = t & 15, c = t >> 4;
+      const int gn = tn + c, gk = k0 + kk;
+      Bs[kk * 64 + c] = (gn < N && gk < K) ? Bm[gk + ldb * gn] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) {
+      const int kk = ks + (lane >> 4);
+      double a[2], b[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        a[q] = As[kk * 64 + wm + q * 16 + (lane & 15)];
+        b[q] = Bs[kk * 64 + wn + q * 16 + (lane & 15)];
+      }
+#pragma unroll
+      for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p], b[q], acc[p][q], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; p++)
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gm = tm + wm + p * 16 + (lane >> 4) + 4 * r;
+        const int gn = tn + wn + q * 16 + (lane & 15);
+        if (gm < M && gn < N) {
+          if (SUBTRACT) C[gm + ldc * gn] -= acc[p][q][r];
+          else C[gm + ldc * gn] = acc[p][q][r];
+        }
+      }
+}
+template <bool SUBTRACT>
+static void gemm_f64(double* C, int64_t ldc, int64_t sC, const double* A, int64_t lda, int64_t sA, const double* Bm, int64_t ldb,
+                     int64_t sB, int M, int N, int K, int batch) {
+  if (M <= 0 || N <= 0 || batch <= 0) return;
+  hipLaunchKernelGGL(k_gemm_f64<SUBTRACT>, dim3((M + 63) / 64, (N + 63) / 64, batch), dim3(256), 0, g_stream, C, ldc, sC, A, lda,
+                     sA, Bm, ldb, sB, M, N, K);
+  launch_check();
+}
+__global__ void k_big_root_update(PlanD P, BatchD B, FrontD F) {
+  const int slot = blockIdx.y;
+  const int w = F.w, ri = F.ri, rs = F.rs, m = w + ri + rs;
+  const double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
+  double* S = B.sblock + (int64_t)slot * P.nS * P.nS;
+  const int32_t* rel = P.rel + F.rel_off;
+  const int64_t tot = (int64_t)rs * rs;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)(t % rs), bb = (int)(t / rs);
+    atomicAdd(&S[rel[ri + a] + (int64_t)P.nS * rel[ri + bb]], A[(w + ri + a) + (int64_t)m * (w + ri + bb)]);
+  }
+}
+
+void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD* kids, int32_t nkids, int32_t b0,
+                      int32_t nbc, const double* kval) {
+  if (nbc <= 0) return;
+  if (nbc > 65535) throw Error(-3, "too many batch members for the big-front path");
+  const int w = F.w, ri = F.ri, rs = F.rs, m = w + ri + rs, r = ri + rs;
+  const int64_t mm = (int64_t)m * m;
+  double* A0 = B.scratch + F.f_off;
+  hipLaunchKernelGGL(k_big_zero, dim3(nblocks(mm, 256, 4096), nbc), dim3(256), 0, g_stream, A0, mm, P.scratch_size); launch_check();
+  if (F.ent_end > F.ent_begin) {
+    hipLaunchKernelGGL(k_big_entries, dim3(nblocks(F.ent_end - F.ent_begin, 256, 256), nbc), dim3(256), 0, g_stream, P, B, F, b0, kval);
+    launch_check();
+  }
+  for (int c = 0; c < nkids; c++) {
+    const int64_t rc = kids[c].ri + kids[c].rs;
+    if (rc <= 0) continue;
+    hipLaunchKernelGGL(k_big_extend_add, dim3(nblocks(rc * rc, 256, 8192), nbc), dim3(256), 0, g_stream, P, B, F, kids[c]);
+    launch_check();
+  }
+  hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(FT), 0, g_stream, P, B, F, b0); launch_check();
+  if (r > 0) {
+    hipLaunchKernelGGL(k_big_trmm_u, dim3((r + 7) / 8, nbc), dim3(256), (size_t)w * 8 * sizeof(double), g_stream, P, B, F); launch_check();
+    hipLaunchKernelGGL(k_big_trmm_l, dim3((r + 7) / 8, nbc), dim3(256), (size_t)w * 8 * sizeof(double), g_stream, P, B, F); launch_check();
+    // Schur update F22 -= L21 U12
+    gemm_f64<true>(A0 + w + (int64_t)m * w, m, P.scratch_size, A0 + w, m, P.scratch_size, A0 + (int64_t)m * w, m, P.scratch_size, r, r, w, nbc);
+    if (ri > 0) {
+      // solve panels: PL = L21_int L11^{-1}, QU = U11^{-1} U12_int (dense inverse copies in tmp)
+      double* fac = B.factor + (int64_t)b0 * P.factor_size;
+      gemm_f64<false>(fac + F.lp_off + w, w + ri, P.factor_size, A0 + w, m, P.scratch_size, B.tmp, w, B.tmp_stride, ri, w, w, nbc);
+      gemm_f64<false>(fac + F.q_off, w, P.factor_size, B.tmp + (int64_t)w * w, w, B.tmp_stride, A0 + (int64_t)m * w, m, P.scratch_size, w, ri, w, nbc);
+    }
+    if (F.parent < 0 && rs > 0) {
+      hipLaunchKernelGGL(k_big_root_update, dim3(nblocks((int64_t)rs * rs, 256, 8192), nbc), dim3(256), 0, g_stream, P, B, F);
+      launch_check();
+    }
+  }
+}
+
+// forward sweep of one big front: every workgroup owns 256 rows of [y ; contrib]; it rebuilds the
+// assembled pivot vector t (w entries) and its own rows of the children's contributions in LDS.
+// y goes to the solve workspace first (other workgroups still read x as t), then k_copy_slice.
+__global__ void __launch_bounds__(256) k_solve_fwd_big(PlanD P, BatchD B, FrontD F, const double* __restrict__ x) {
+  extern __shared__ double sh[];   // t[w] | mine[256]
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int w = F.w, ri = F.ri, rows = w + ri;
+  const int64_t ld = rows;
+  double* t = sh;
+  double* mine = sh + w;
+  const double* xb = x + B.xoff[b];
+  double* cb = B.contrib + (int64_t)b * P.contrib_size;
+  double* yw = B.swork + (int64_t)b * B.swork_stride;
+  const int r0 = blockIdx.x * 256;
+  for (int j = tid; j < w; j += 256) t[j] = xb[F.c0 + j];
+  mine[tid] = 0.0;
+  __syncthreads();
+  for (int ce = F.child_begin; ce < F.child_end; ce++) {
+    const FrontD Cf = P.fronts[P.children[ce]];
+    const int32_t* rel = P.rel + Cf.rel_off;
+    for (int k = tid; k < Cf.ri; k += 256) {
+      const int pos = rel[k];
+      const double v = cb[Cf.c_off + k];
+      if (pos < w) t[pos] += v;                      // positions of one child are unique
+      else if (pos >= r0 && pos < r0 + 256) mine[pos - r0] += v;
+    }
+    __syncthreads();
+  }
+  const int i = r0 + tid;
+  if (i >= rows) return;
+  const double* __restrict__ Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off + i;
+  const int kmax = i < w ? i : w;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = 0;
+  for (; k + 3 < kmax; k += 4) {
+    a0 += Lp[ld * k] * t[k];
+    a1 += Lp[ld * (k + 1)] * t[k + 1];
+    a2 += Lp[ld * (k + 2)] * t[k + 2];
+    a3 += Lp[ld * (k + 3)] * t[k + 3];
+  }
+  for (; k < kmax; k++) a0 += Lp[ld * k] * t[k];
+  const double sum = (a0 + a1) + (a2 + a3);
+  if (i < w) yw[i] = t[i] + sum;
+  else cb[F.c_off + i - w] = mine[tid] - sum;
+}
+__global__ void k_copy_slice(BatchD B, int32_t c0, int32_t w, double* __restrict__ x) {
+  const int b = blockIdx.y;
+  const double* yw = B.swork + (int64_t)b * B.swork_stride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w; i += gridDim.x * blockDim.x) x[B.xoff[b] + c0 + i] = yw[i];
+}
+void solve_fwd_big(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD*, int32_t, double* x) {
+  if (B.nb <= 0) return;
+  if (B.nb > 65535) throw Error(-3, "too many batch members for the big-front path");
+  const int rows = F.w + F.ri;
+  hipLaunchKernelGGL(k_solve_fwd_big, dim3((rows + 255) / 256, B.nb), dim3(256), (size_t)(F.w + 256) * sizeof(double), g_stream, P, B, F, x);
+  launch_check();
+  hipLaunchKernelGGL(k_copy_slice, dim3((F.w + 255) / 256, B.nb), dim3(256), 0, g_stream, B, F.c0, F.w, x);
+  launch_check();
+}
+// backward sweep of one big front, split over the long k range: partial sums per chunk of 256
+// columns into the workspace, then a fixed-order reduction (bitwise reproducible)
+__global__ void __launch_bounds__(256) k_solve_bwd_big(PlanD P, BatchD B, FrontD F, const double* __restrict__ x) {
+  __shared__ double xs[256];
+  const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+  const int w = F.w, ri = F.ri;
+  const int64_t ld = w + ri;
+  const double* xb = x + B.xoff[b];
+  const double* fac = B.factor + (int64_t)b * P.factor_size;
+  double* part = B.swork + (int64_t)b * B.swork_stride + (int64_t)chunk * w;
+  if (chunk == 0) {
+    // pivot block: x_i = sum_{k >= i} Uinv[i,k] y_k ; y staged through LDS in slabs of 256
+    const double* __restrict__ Lp = fac + F.lp_off;
+    for (int i0 = 0; i0 < w; i0 += 256) {
+      const int i = i0 + tid;
+      double s = 0.0;
+      for (int k0 = i0; k0 < w; k0 += 256) {
+        __syncthreads();
+        xs[tid] = (k0 + tid < w) ? xb[F.c0 + k0 + tid] : 0.0;
+        __syncthreads();
+        if (i < w) {
+          const int kb = max(k0, i), ke = min(k0 + 256, w);
+          for (int k = kb; k < ke; k++) s += Lp[i + ld * k] * xs[k - k0];
+        }
+      }
+      if (i < w) part[i] = s;
+    }
+    return;
+  }
+  const int k0 = (chunk - 1) * 256, nk = min(256, ri - k0);
+  const int32_t* __restrict__ idx = P.fidx + F.idx_off + w + k0;
+  xs[tid] = tid < nk ? xb[idx[tid]] : 0.0;
+  __syncthreads();
+  const double* __restrict__ Q = fac + F.q_off + (int64_t)w * k0;
+  for (int i = tid; i < w; i += 256) {
+    double a0 = 0.0, a1 = 0.0;
+    int k = 0;
+    for (; k + 1 < nk; k += 2) { a0 += Q[i + (int64_t)w * k] * xs[k]; a1 += Q[i + (int64_t)w * (k + 1)] * xs[k + 1]; }
+    if (k < nk) a0 += Q[i + (int64_t)w * k] * xs[k];
+    part[i] = -(a0 + a1);
+  }
+}
+__global__ void k_reduce_chunks(BatchD B, int32_t c0, int32_t w, int32_t nchunk, double* __restrict__ x) {
+  const int b = blockIdx.y;
+  const double* part = B.swork + (int64_t)b * B.swork_stride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w; i += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int c = 0; c < nchunk; c++) s += part[(int64_t)c * w + i];
+    x[B.xoff[b] + c0 + i] = s;
+  }
+}
+void solve_bwd_big(const PlanD& P, const BatchD& B, const FrontD& F, double* x) {
+  if (B.nb <= 0) return;
+  if (B.nb > 65535) throw Error(-3, "too many batch members for the big-front path");
+  const int nchunk = 1 + (F.ri + 255) / 256;
+  if ((int64_t)nchunk * F.w > B.swork_stride) throw Error(-3, "solve workspace too small for a big front");
+  hipLaunchKernelGGL(k_solve_bwd_big, dim3(nchunk, B.nb), dim3(256), 0, g_stream, P, B, F, x); launch_check();
+  hipLaunchKernelGGL(k_reduce_chunks, dim3((F.w + 255) / 256, B.nb), dim3(256), 0, g_stream, B, F.c0, F.w, nchunk, x); launch_check();
+}
+
 // ------------------------------------------------------------------ solves
 // forward: [y ; contrib] = [L11^{-1} ; -L21 L11^{-1}] * t, t assembled from x and the children
 __global__ void __launch_bounds__(256) k_solve_fwd(PlanD P, BatchD B, const int32_t* __restrict__ list, double* __restrict__ x) {

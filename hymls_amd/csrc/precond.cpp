@@ -26,6 +26,7 @@ inline void gid_coord(const Params& p, int32_t gid, int32_t* c) {
 
 constexpr int LEAF_SIZE = 24;
 constexpr int MAX_WIDTH = 256;
+constexpr int MAX_WIDTH_COARSE = 256;
 constexpr int64_t SCRATCH_BUDGET = 1LL << 30;  // doubles (8 GiB) of frontal scratch per pass
 
 }  // namespace
@@ -83,7 +84,11 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   dplan.s_ent_begin = plan.s_ent_begin; dplan.s_ent_end = nent;
   dplan.scratch_size = plan.scratch_size; dplan.factor_size = plan.factor_size;
   dplan.contrib_size = plan.contrib_size;
-  dplan.max_solve_rows = std::max(plan.max_solve_rows, 1);
+  {
+    int32_t msr = 1;  // LDS vector of the one-workgroup-per-front solve kernels: small fronts only
+    for (auto& F : plan.fronts) if (!F.big) msr = std::max(msr, F.w + F.ri);
+    dplan.max_solve_rows = msr;
+  }
   for (auto& L : plan.levels) d_lists.push_back(keep(dev::upload(L)));
   const int64_t per = plan.scratch_size + (with_sblock ? (int64_t)plan.nS * plan.nS : 0);
   chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nb, budget / std::max<int64_t>(per, 1)));
@@ -98,18 +103,48 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   batch.contrib = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)nb * plan.contrib_size) * sizeof(double)));
   batch.flag = (int32_t*)keep(dev::alloc(sizeof(int32_t)));
   dev::zero(batch.flag, sizeof(int32_t));
+  h_fronts = fd;
+  bool any_big = false;
+  for (auto& L : plan.big_levels) any_big |= !L.empty();
+  batch.tmp = nullptr; batch.tmp_stride = 0; batch.swork = nullptr; batch.swork_stride = 0;
+  if (any_big) {
+    batch.tmp_stride = 2LL * plan.max_w * plan.max_w;
+    batch.tmp = (double*)keep(dev::alloc((size_t)chunk * batch.tmp_stride * sizeof(double)));
+    batch.swork_stride = 2LL * (plan.max_solve_rows + 64) * 64;
+    batch.swork = (double*)keep(dev::alloc((size_t)nb * batch.swork_stride * sizeof(double)));
+  }
+}
+
+std::vector<dev::FrontD> BatchedLU::kids_of(int s) const {
+  std::vector<dev::FrontD> k;
+  for (int e = plan.fronts[s].child_begin; e < plan.fronts[s].child_end; e++) k.push_back(h_fronts[plan.children[e]]);
+  return k;
 }
 
 void BatchedLU::factor_chunk(const double* kval, int32_t b0, int32_t nbc) {
   if (batch.sblock) dev::sblock_init(dplan, batch, b0, nbc, kval);
-  for (size_t l = 0; l < plan.levels.size(); l++)
+  for (size_t l = 0; l < plan.levels.size(); l++) {
     dev::factor_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), b0, nbc, kval);
+    for (int s : plan.big_levels[l]) {
+      auto k = kids_of(s);
+      dev::factor_big_front(dplan, batch, h_fronts[s], k.data(), (int32_t)k.size(), b0, nbc, kval);
+    }
+  }
 }
 
 void BatchedLU::solve(double* x) const {
   const int nl = (int)plan.levels.size();
-  for (int l = 0; l < nl; l++) dev::solve_fwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
-  for (int l = nl - 1; l >= 0; l--) dev::solve_bwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
+  for (int l = 0; l < nl; l++) {
+    dev::solve_fwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
+    for (int s : plan.big_levels[l]) {
+      auto k = kids_of(s);
+      dev::solve_fwd_big(dplan, batch, h_fronts[s], k.data(), (int32_t)k.size(), x);
+    }
+  }
+  for (int l = nl - 1; l >= 0; l--) {
+    for (int s : plan.big_levels[l]) dev::solve_bwd_big(dplan, batch, h_fronts[s], x);
+    dev::solve_bwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
+  }
 }
 
 int32_t BatchedLU::check_flag() const {
@@ -148,7 +183,7 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   for (int i = 0; i < n_; i++) gid_coord(cp, gids[i], &lp.coord[3 * (size_t)i]);
   (void)ngid;
   lu_.reset(new BatchedLU());
-  lu_->plan = analyse_class(lp, LEAF_SIZE, MAX_WIDTH);
+  lu_->plan = analyse_class(lp, LEAF_SIZE, MAX_WIDTH_COARSE);
   lu_->members = {0};
   lu_->h_xoff = {0};
   // entry e of the extended CSR is entry e of A
@@ -569,7 +604,9 @@ void LevelSolver::build_schur_setup() {
     Cls& C = *cls_[c];
     plans.push_back(C.lu.dplan);
     const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + dev::FUSED_MAX_ROWS;
-    if (C.lu.plan.max_solve_rows > dev::FUSED_MAX_ROWS || need > LDS_CAP || C.lu.plan.nI == 0) continue;
+    bool any_big = false;
+    for (auto& L : C.lu.plan.big_levels) any_big |= !L.empty();
+    if (any_big || C.lu.plan.max_solve_rows > dev::FUSED_MAX_ROWS || need > LDS_CAP || C.lu.plan.nI == 0) continue;
     cls_fused_[c] = 1;
     fused_lds_ = std::max(fused_lds_, need);
     for (size_t b = 0; b < C.lu.members.size(); b++)

@@ -28,6 +28,8 @@ struct BatchedLU {
   dev::PlanD dplan{};
   dev::BatchD batch{};
   std::vector<int32_t*> d_lists;  // per tree level
+  std::vector<dev::FrontD> h_fronts;  // host copies (grid setup of the big-front kernels)
+  std::vector<dev::FrontD> kids_of(int s) const;
   std::vector<void*> owned;       // device allocations to free
   int32_t nent = 0;
   int32_t chunk = 0;              // members factored per pass

@@ -188,7 +188,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width) {
     maxlev = std::max(maxlev, lv);
   }
   P.levels.assign(nf ? maxlev + 1 : 0, ivec());
-  for (int s = 0; s < nf; s++) P.levels[P.fronts[s].level].push_back(s);
+  P.big_levels.assign(nf ? maxlev + 1 : 0, ivec());
   // --- index lists, offsets
   int64_t foff = 0, fac = 0;
   int32_t coff = 0;
@@ -206,6 +206,14 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width) {
     F.q_off = fac; fac += (int64_t)F.w * F.ri;
     F.c_off = coff; coff += F.ri;
     P.max_front = std::max<int32_t>(P.max_front, (int32_t)m);
+    P.max_w = std::max<int32_t>(P.max_w, F.w);
+    {
+      // a front whose Schur update is too much work for one workgroup goes to the multi-workgroup path
+      const double r = F.ri + F.rs;
+      static const double big_flops = std::getenv("HYMLS_MI_BIG_FLOPS") ? std::atof(std::getenv("HYMLS_MI_BIG_FLOPS")) : 2.5e7;
+      F.big = r * r * F.w > big_flops || m > 2048;
+      (F.big ? P.big_levels : P.levels)[F.level].push_back(s);
+    }
     P.max_solve_rows = std::max<int32_t>(P.max_solve_rows, F.w + F.ri);
     P.nnz_factor += (int64_t)F.w * F.w + 2LL * F.w * F.ri;
     const double w = F.w, r = F.ri + F.rs;

@@ -40,6 +40,7 @@ struct Front {
   int32_t c_off = 0;          // contribution vector (ri) in the per-subdomain solve scratch
   int32_t ent_begin = 0, ent_end = 0;  // matrix entries assembled into this front
   int32_t child_begin = 0, child_end = 0;  // into ClassPlan::children
+  bool big = false;            // processed by the multi-workgroup kernels
   int32_t m() const { return w + ri + rs; }
 };
 
@@ -53,7 +54,9 @@ struct ClassPlan {
   ivec rel;                   // per front: its update rows located in the parent's index list
                               // (parent == -1: separator local id)
   ivec children;              // child front ids grouped per front
-  std::vector<ivec> levels;   // front ids per tree level (leaves = 0)
+  std::vector<ivec> levels;   // front ids per tree level (leaves = 0): fronts handled by one workgroup each
+  std::vector<ivec> big_levels;  // per tree level: fronts spread over many workgroups
+  int32_t max_w = 0;
   // matrix entry assembly: sorted by front; S-block entries last (front == nfronts)
   ivec ent_id;                // entry number in the extended CSR
   ivec ent_pos;               // position in the front (row + m*col) or in S (row + nS*col)

@@ -56,12 +56,8 @@ void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const
   }
 }
 
-void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, int32_t b0, int32_t nbc,
-                  const double* kval) {
-  for (int slot = 0; slot < nbc; slot++)
-    for (int q = 0; q < count; q++) {
-      const int b = b0 + slot;
-      const FrontD& F = P.fronts[list[q]];
+static void sim_factor_front(const PlanD& P, const BatchD& B, const FrontD& F, int slot, int b, const double* kval) {
+    {
       const int w = F.w, ri = F.ri, rs = F.rs, m = w + ri + rs;
       double* sc = B.scratch + (int64_t)slot * P.scratch_size;
       double* A = sc + F.f_off;
@@ -127,11 +123,19 @@ void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t 
     }
 }
 
-void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
+void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, int32_t b0, int32_t nbc,
+                  const double* kval) {
+  for (int slot = 0; slot < nbc; slot++)
+    for (int q = 0; q < count; q++) sim_factor_front(P, B, P.fronts[list[q]], slot, b0 + slot, kval);
+}
+void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD*, int32_t, int32_t b0, int32_t nbc,
+                      const double* kval) {
+  for (int slot = 0; slot < nbc; slot++) sim_factor_front(P, B, F, slot, b0 + slot, kval);
+}
+
+static void sim_fwd_front(const PlanD& P, const BatchD& B, const FrontD& F, int b, double* x) {
   std::vector<double> f;
-  for (int b = 0; b < B.nb; b++)
-    for (int q = 0; q < count; q++) {
-      const FrontD& F = P.fronts[list[q]];
+    {
       const int w = F.w, ri = F.ri, ld = w + ri;
       f.assign(ld, 0.0);
       double* xb = x + B.xoff[b];
@@ -156,11 +160,16 @@ void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32
     }
 }
 
-void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
+void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
+  for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_fwd_front(P, B, P.fronts[list[q]], b, x);
+}
+void solve_fwd_big(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD*, int32_t, double* x) {
+  for (int b = 0; b < B.nb; b++) sim_fwd_front(P, B, F, b, x);
+}
+
+static void sim_bwd_front(const PlanD& P, const BatchD& B, const FrontD& F, int b, double* x) {
   std::vector<double> g, out;
-  for (int b = 0; b < B.nb; b++)
-    for (int q = 0; q < count; q++) {
-      const FrontD& F = P.fronts[list[q]];
+    {
       const int w = F.w, ri = F.ri, ld = w + ri;
       double* xb = x + B.xoff[b];
       g.resize(ld); out.resize(w);
@@ -177,6 +186,13 @@ void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32
       }
       for (int i = 0; i < w; i++) xb[F.c0 + i] = out[i];
     }
+}
+
+void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
+  for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_bwd_front(P, B, P.fronts[list[q]], b, x);
+}
+void solve_bwd_big(const PlanD& P, const BatchD& B, const FrontD& F, double* x) {
+  for (int b = 0; b < B.nb; b++) sim_bwd_front(P, B, F, b, x);
 }
 
 void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t, double* x) {

@@ -141,3 +141,35 @@ def test_errors(gpu_lib):
     with pytest.raises(hymls_amd.HymlsError) as e:
         P.Compute()
     assert e.value.code == -4
+
+
+def test_big_front_path_matches_oracle():
+    """Force the multi-workgroup ("big front") factor/solve kernels (MFMA FP64 Schur update,
+    row-chunked forward, split-k backward) on small problems by lowering the work threshold in a
+    fresh process, and compare with the oracle."""
+    import os, subprocess, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, "tests")
+from common import problem, xml_params, oracle_prec, product_prec, rel_diff
+import hymls_amd
+lib = hymls_amd.load_library()
+for (eq, n, sx, levels, part, tol) in [("Laplace", 16, 4, 1, "Cartesian", 1e-10), ("Laplace", 32, 8, 1, "Cartesian", 1e-10),
+                                      ("Stokes-C", 16, 8, 1, "Skew Cartesian", 1e-8), ("Stokes-C", 16, 4, 2, "Skew Cartesian", 1e-8)]:
+    A, tv = problem(eq, n)
+    cx = 2 if levels == 2 else -1
+    P = product_prec(A, tv, xml_params(eq, n, sx, levels, cx, part), lib)
+    O = oracle_prec(A, tv, eq, n, sx, levels, cx, partitioner=part)
+    b = np.random.default_rng(12).uniform(-1, 1, A.shape[0])
+    d = rel_diff(P.ApplyInverse(b), O.apply_inverse(b))
+    print(eq, n, sx, levels, d)
+    assert d < tol, (eq, n, sx, levels, d)
+print("BIG-OK")
+'''
+    env = dict(os.environ, HYMLS_MI_BIG_FLOPS="3000")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "BIG-OK" in out.stdout, out.stdout + out.stderr

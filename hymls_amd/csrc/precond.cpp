@@ -27,6 +27,7 @@ inline void gid_coord(const Params& p, int32_t gid, int32_t* c) {
 constexpr int LEAF_SIZE = 24;
 constexpr int MAX_WIDTH = 256;
 constexpr int MAX_WIDTH_COARSE = 256;
+constexpr int LEAF_SIZE_COARSE = 64;
 constexpr int64_t SCRATCH_BUDGET = 1LL << 30;  // doubles (8 GiB) of frontal scratch per pass
 
 }  // namespace
@@ -183,7 +184,8 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   for (int i = 0; i < n_; i++) gid_coord(cp, gids[i], &lp.coord[3 * (size_t)i]);
   (void)ngid;
   lu_.reset(new BatchedLU());
-  lu_->plan = analyse_class(lp, LEAF_SIZE, MAX_WIDTH_COARSE);
+  lu_->plan = analyse_class(lp, LEAF_SIZE_COARSE, MAX_WIDTH_COARSE, 65536);
+  if (std::getenv("HYMLS_MI_VERBOSE")) print_plan_stats(lu_->plan, "coarse solver", 1);
   lu_->members = {0};
   lu_->h_xoff = {0};
   // entry e of the extended CSR is entry e of A
@@ -431,6 +433,11 @@ void LevelSolver::build_classes() {
     n1_ += C.pat.nI;
   }
   for (int k = 0; k < n2_; k++) in_perm_[n1_ + k] = sep_row_[k];
+  if (std::getenv("HYMLS_MI_VERBOSE")) {
+    std::fprintf(stderr, "[hymls_mi] level %d: n %d subdomains %d classes %zu n1 %d n2 %d\n", level_, n, nsd, cls_.size(), n1_, n2_);
+    size_t shown = 0;
+    for (auto& c : cls_) if (shown++ < 4 || c->lu.members.size() > 50) print_plan_stats(c->lu.plan, "  class", (int)c->lu.members.size());
+  }
 }
 
 void LevelSolver::build_schur_setup() {

@@ -79,7 +79,15 @@ void nd_recurse(NdCtx& c, ivec& nodes) {
 
 }  // namespace
 
-ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width) {
+void print_plan_stats(const ClassPlan& P, const char* label, int nmembers) {
+  int nbig = 0, maxw = 0, maxr = 0;
+  for (auto& F : P.fronts) { nbig += F.big; maxw = std::max(maxw, F.w); maxr = std::max(maxr, F.ri + F.rs); }
+  std::fprintf(stderr, "[hymls_mi] %s: members %d nI %d nS %d fronts %zu (big %d) levels %zu max_w %d max_r %d nnz_factor %.3g scratch %.3g MB flops %.3g\n",
+               label, nmembers, P.nI, P.nS, P.fronts.size(), nbig, P.levels.size(), maxw, maxr, (double)P.nnz_factor,
+               8e-6 * (double)P.scratch_size, (double)P.flops_factor);
+}
+
+ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, int64_t big_panel_entries) {
   ClassPlan P;
   const int nI = lp.nI, nS = lp.nS, n = nI + nS;
   P.nI = nI; P.nS = nS;
@@ -211,7 +219,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width) {
       // a front whose Schur update is too much work for one workgroup goes to the multi-workgroup path
       const double r = F.ri + F.rs;
       static const double big_flops = std::getenv("HYMLS_MI_BIG_FLOPS") ? std::atof(std::getenv("HYMLS_MI_BIG_FLOPS")) : 2.5e7;
-      F.big = r * r * F.w > big_flops || m > 2048;
+      F.big = r * r * F.w > big_flops || m > 2048 || (int64_t)(F.w + F.ri) * F.w > big_panel_entries;
       (F.big ? P.big_levels : P.levels)[F.level].push_back(s);
     }
     P.max_solve_rows = std::max<int32_t>(P.max_solve_rows, F.w + F.ri);

@@ -73,6 +73,7 @@ struct ClassPlan {
 
 // throws hymls::Error(-4, ...) if the pressure nodes cannot all be attached
 // (structurally singular interior block).
-ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width);
+ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, int64_t big_panel_entries = (int64_t)1 << 40);
+void print_plan_stats(const ClassPlan& P, const char* label, int nmembers);
 
 }  // namespace hymls

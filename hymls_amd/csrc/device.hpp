@@ -35,7 +35,7 @@ T* upload(const std::vector<T>& v) {
 // ---- device-side plan of one pattern class (POD, arrays live on the device)
 struct FrontD {
   int32_t c0, w, ri, rs;
-  int32_t parent, idx_off, rel_off, c_off;
+  int32_t parent, idx_off, rel_off, c_off, a_off;
   int32_t ent_begin, ent_end, child_begin, child_end;
   int64_t f_off, lp_off, q_off;
 };
@@ -49,6 +49,9 @@ struct PlanD {
   const int32_t* ent_id;
   const int32_t* ent_pos;
   const double* ent_w;
+  const int32_t* asm_ptr;   // [asm_rows + 1]
+  const int32_t* asm_src;
+  int32_t asm_rows;
   int32_t s_ent_begin, s_ent_end;
   int64_t scratch_size, factor_size;
   int32_t contrib_size;
@@ -65,9 +68,9 @@ struct BatchD {
   double* sblock;        // [chunk][nS*nS]          separator (Schur) block, col-major
   double* contrib;       // [nb][contrib_size]      solve scratch
   int32_t* flag;         // device int: set != 0 on zero / non-finite pivot
-  double* tmp;           // [chunk][2*max_w*max_w] dense copies of the pivot-block inverses (big fronts)
+  double* tmp;           // [chunk][tmp_stride] dense pivot-piece inverses + panel scratch (big fronts)
   int64_t tmp_stride;
-  double* swork;         // [nb][swork_stride] solve workspace of the big fronts
+  double* swork;         // [nb][swork_stride] solve workspace: assembled rows, then nI outputs
   int64_t swork_stride;
 };
 
@@ -92,11 +95,14 @@ void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t 
 // separator block: S = weighted A22 entries (call before the tree), per batch member
 void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const double* kval);
 
-// one big front, spread over many workgroups (kids: host copies of its children)
+// one big front (supernode), spread over many workgroups: its pivot block is factored in pieces
+// of `piece` columns in place, then inverted explicitly (kids: host copies of its children)
+constexpr int PIECE = 256;
 void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD* kids, int32_t nkids,
                       int32_t b0, int32_t nbc, const double* kval);
-void solve_fwd_big(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD* kids, int32_t nkids, double* x);
-void solve_bwd_big(const PlanD& P, const BatchD& B, const FrontD& F, double* x);
+// all big fronts of one tree level (device list of front ids, host copies for the grid sizes)
+void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hfronts, int32_t count, double* x);
+void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hfronts, int32_t count, double* x);
 
 // ---- solves with the factor panels; x is the level vector (interior part), in place
 void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x);

@@ -432,97 +432,102 @@ __global__ void k_big_extend_add(PlanD P, BatchD B, FrontD F, FrontD Cf) {
     A[rel[a] + (int64_t)m * rel[bb]] += Ac[(Cf.w + a) + (int64_t)mc * (Cf.w + bb)];
   }
 }
-// LU of the pivot block + packed inverses into the factor slab + dense copies (Linv | Uinv) in tmp
-__global__ void __launch_bounds__(FT) k_big_pivot(PlanD P, BatchD B, FrontD F, int32_t b0) {
+// LU (no pivoting) of one wk x wk pivot piece at A (leading dimension ld), its triangular inverses
+// packed into the supernode's slab block (strictly lower = L^{-1}, upper = U^{-1}) and as dense
+// copies Lf (unit lower) / Uf (upper) for the panel products.  One workgroup per batch slot.
+__global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64_t ld, int64_t strideA, int wk,
+                                                  double* __restrict__ slab0, int64_t lds, int64_t strideS,
+                                                  double* __restrict__ tmp0, int64_t strideT, int32_t* flag) {
   __shared__ int s_bad;
-  const int tid = threadIdx.x, slot = blockIdx.x, b = b0 + slot;
-  const int w = F.w, m = F.w + F.ri + F.rs;
-  double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
+  const int tid = threadIdx.x, slot = blockIdx.x;
+  double* A = A0 + (int64_t)slot * strideA;
+  double* Sb = slab0 + (int64_t)slot * strideS;
+  double* Lf = tmp0 + (int64_t)slot * strideT;
+  double* Uf = Lf + (int64_t)PIECE * PIECE;
+  const int w = wk;
   if (tid == 0) s_bad = 0;
   __syncthreads();
   for (int k = 0; k < w; k++) {
-    const double piv = A[k + (int64_t)m * k];
+    const double piv = A[k + ld * k];
     if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
     const double ip = 1.0 / piv;
     __syncthreads();
-    for (int i = k + 1 + tid; i < w; i += FT) A[i + (int64_t)m * k] *= ip;
+    for (int i = k + 1 + tid; i < w; i += FT) A[i + ld * k] *= ip;
     __syncthreads();
     const int rem = w - k - 1;
     for (int t = tid; t < rem * rem; t += FT) {
       const int i = k + 1 + t % rem, j = k + 1 + t / rem;
-      A[i + (int64_t)m * j] -= A[i + (int64_t)m * k] * A[k + (int64_t)m * j];
+      A[i + ld * j] -= A[i + ld * k] * A[k + ld * j];
     }
     __syncthreads();
   }
-  if (s_bad && tid == 0) atomicExch(B.flag, 1);
-  double* Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off;
-  const int64_t ld = F.w + F.ri;
-  double* Lf = B.tmp + (int64_t)slot * B.tmp_stride;   // dense L11^{-1} (w x w)
-  double* Uf = Lf + (int64_t)w * w;                    // dense U11^{-1}
+  if (s_bad && tid == 0) atomicExch(flag, 1);
   for (int t = tid; t < w; t += FT) {
     for (int i = 0; i < t; i++) Lf[i + (int64_t)w * t] = 0.0;
     Lf[t + (int64_t)w * t] = 1.0;
     for (int i = t + 1; i < w; i++) {
-      double s = A[i + (int64_t)m * t];
-      for (int j = t + 1; j < i; j++) s += A[i + (int64_t)m * j] * Lp[j + ld * t];
-      Lp[i + ld * t] = -s;
+      double s = A[i + ld * t];
+      for (int j = t + 1; j < i; j++) s += A[i + ld * j] * Lf[j + (int64_t)w * t];
       Lf[i + (int64_t)w * t] = -s;
+      Sb[i + lds * t] = -s;
     }
-    const double d = 1.0 / A[t + (int64_t)m * t];
-    Lp[t + ld * t] = d;
+    const double d = 1.0 / A[t + ld * t];
     Uf[t + (int64_t)w * t] = d;
+    Sb[t + lds * t] = d;
     for (int i = t + 1; i < w; i++) Uf[i + (int64_t)w * t] = 0.0;
     for (int i = t - 1; i >= 0; i--) {
       double s = 0.0;
-      for (int j = i + 1; j <= t; j++) s += A[i + (int64_t)m * j] * Lp[j + ld * t];
-      const double v = -s / A[i + (int64_t)m * i];
-      Lp[i + ld * t] = v;
+      for (int j = i + 1; j <= t; j++) s += A[i + ld * j] * Uf[j + (int64_t)w * t];
+      const double v = -s / A[i + ld * i];
       Uf[i + (int64_t)w * t] = v;
+      Sb[i + lds * t] = v;
     }
   }
 }
-// U12 = L11^{-1} F12 in place: one workgroup per block of 8 columns
-__global__ void __launch_bounds__(256) k_big_trmm_u(PlanD P, BatchD B, FrontD F) {
+// row panel right of a pivot piece: U12 = L^{-1} F12 in place, one workgroup per 8 columns
+__global__ void __launch_bounds__(256) k_big_trmm_u(double* __restrict__ A0, int64_t ld, int64_t strideA, int wk, int rk,
+                                                    const double* __restrict__ tmp0, int64_t strideT) {
   extern __shared__ double st[];
-  const int slot = blockIdx.y, tid = threadIdx.x;
-  const int w = F.w, m = F.w + F.ri + F.rs, r = F.ri + F.rs;
-  double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
-  const double* Lf = B.tmp + (int64_t)slot * B.tmp_stride;
-  const int j0 = blockIdx.x * 8, nc = min(8, r - j0);
-  for (int t = tid; t < w * nc; t += 256) st[t] = A[(t % w) + (int64_t)m * (w + j0 + t / w)];
+  const int slot = blockIdx.y, tid = threadIdx.x, w = wk;
+  double* A = A0 + (int64_t)slot * strideA;                 // points at the piece's diagonal block
+  const double* Lf = tmp0 + (int64_t)slot * strideT;
+  const int j0 = blockIdx.x * 8, nc = min(8, rk - j0);
+  for (int t = tid; t < w * nc; t += 256) st[t] = A[(t % w) + ld * (w + j0 + t / w)];
   __syncthreads();
   for (int t = tid; t < w * nc; t += 256) {
     const int i = t % w, j = t / w;
     double s = st[i + w * j];
     for (int k = 0; k < i; k++) s += Lf[i + (int64_t)w * k] * st[k + w * j];
-    A[i + (int64_t)m * (w + j0 + j)] = s;
+    A[i + ld * (w + j0 + j)] = s;
   }
 }
-// L21 = F21 U11^{-1} in place: one workgroup per block of 8 rows
-__global__ void __launch_bounds__(256) k_big_trmm_l(PlanD P, BatchD B, FrontD F) {
+// column panel below a pivot piece: L21 = F21 U^{-1} in place, one workgroup per 8 rows
+__global__ void __launch_bounds__(256) k_big_trmm_l(double* __restrict__ A0, int64_t ld, int64_t strideA, int wk, int rk,
+                                                    const double* __restrict__ tmp0, int64_t strideT) {
   extern __shared__ double st[];
-  const int slot = blockIdx.y, tid = threadIdx.x;
-  const int w = F.w, m = F.w + F.ri + F.rs, r = F.ri + F.rs;
-  double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
-  const double* Uf = B.tmp + (int64_t)slot * B.tmp_stride + (int64_t)w * w;
-  const int i0 = blockIdx.x * 8, nr = min(8, r - i0);
-  for (int t = tid; t < nr * w; t += 256) st[t] = A[(w + i0 + t % nr) + (int64_t)m * (t / nr)];
+  const int slot = blockIdx.y, tid = threadIdx.x, w = wk;
+  double* A = A0 + (int64_t)slot * strideA;
+  const double* Uf = tmp0 + (int64_t)slot * strideT + (int64_t)PIECE * PIECE;
+  const int i0 = blockIdx.x * 8, nr = min(8, rk - i0);
+  for (int t = tid; t < nr * w; t += 256) st[t] = A[(w + i0 + t % nr) + ld * (t / nr)];
   __syncthreads();
   for (int t = tid; t < nr * w; t += 256) {
     const int i = t % nr, j = t / nr;
     double s = 0.0;
     for (int k = 0; k <= j; k++) s += st[i + nr * k] * Uf[k + (int64_t)w * j];
-    A[(w + i0 + i) + (int64_t)m * j] = s;
+    A[(w + i0 + i) + ld * j] = s;
   }
 }
 
-// C (MxN) = C - A B  or  C = A B on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), column-major.
-// 64x64 tile per workgroup, each of the 4 waves owns a 32x32 quadrant = 2x2 MFMA tiles; A and B
-// slabs of 16 in K are staged through LDS (k-major so that every MFMA operand read is conflict
-// free).  Lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; result register r
-// holds D[row = (l >> 4) + 4 r][col = l & 15] (f64 layout, cdna_hip_programming.md section 3).
+// C (MxN) = A B | C - A B | -(A B) on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), column-major.
+// 64x64 tile per workgroup, each of the 4 waves owns a 32x32 quadrant = 2x2 MFMA tiles; slabs of
+// 16 in K are staged through LDS k-major.  Lane l holds A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; result register r holds D[row = (l >> 4) + 4 r][col = l & 15]
+// (f64 layout, cdna_hip_programming.md section 3).  MA / MB mask a triangular operand that is
+// stored packed with its sibling triangle: 1 = unit lower (above diagonal 0, diagonal 1),
+// 2 = upper (below diagonal 0).
 typedef double d4 __attribute__((ext_vector_type(4)));
-template <bool SUBTRACT>
+template <int MODE, int MA, int MB>
 __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_t ldc, int64_t strideC,
                                                    const double* __restrict__ A, int64_t lda, int64_t strideA,
                                                    const double* __restrict__ Bm, int64_t ldb, int64_t strideB,
@@ -538,17 +543,29 @@ __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  // triangular operands: skip the K slabs that are entirely zero for this tile
+  int kbeg = 0, kend = K;
+  if (MA == 1) kend = min(K, tm + 64);          // A lower: columns beyond the tile's last row are zero
+  if (MA == 2) kbeg = max(0, (tm / 16) * 16);   // A upper: columns before the tile's first row are zero
+  if (MB == 1) kbeg = max(kbeg, (tn / 16) * 16);  // B lower: rows above the tile's first column are zero
+  if (MB == 2) kend = min(kend, tn + 64);         // B upper: rows below the tile's last column are zero
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
     __syncthreads();
     for (int t = tid; t < 16 * 64; t += 256) {
       const int r = t & 63, kk = t >> 6;
       const int gm = tm + r, gk = k0 + kk;
-      As[kk * 64 + r] = (gm < M && gk < K) ? A[gm + lda * gk] : 0.0;
+      double v = (gm < M && gk < K) ? A[gm + lda * gk] : 0.0;
+      if (MA == 1) v = gk > gm ? 0.0 : (gk == gm ? 1.0 : v);
+      if (MA == 2) v = gk < gm ? 0.0 : v;
+      As[kk * 64 + r] = v;
     }
     for (int t = tid; t < 16 * 64; t += 256) {
       const int kk = t & 15, c = t >> 4;
       const int gn = tn + c, gk = k0 + kk;
-      Bs[kk * 64 + c] = (gn < N && gk < K) ? Bm[gk + ldb * gn] : 0.0;
+      double v = (gn < N && gk < K) ? Bm[gk + ldb * gn] : 0.0;
+      if (MB == 1) v = gn > gk ? 0.0 : (gn == gk ? 1.0 : v);
+      if (MB == 2) v = gn < gk ? 0.0 : v;
+      Bs[kk * 64 + c] = v;
     }
     __syncthreads();
 #pragma unroll
@@ -575,17 +592,18 @@ __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_
         const int gm = tm + wm + p * 16 + (lane >> 4) + 4 * r;
         const int gn = tn + wn + q * 16 + (lane & 15);
         if (gm < M && gn < N) {
-          if (SUBTRACT) C[gm + ldc * gn] -= acc[p][q][r];
+          if (MODE == 1) C[gm + ldc * gn] -= acc[p][q][r];
+          else if (MODE == 2) C[gm + ldc * gn] = -acc[p][q][r];
           else C[gm + ldc * gn] = acc[p][q][r];
         }
       }
 }
-template <bool SUBTRACT>
+template <int MODE, int MA, int MB>
 static void gemm_f64(double* C, int64_t ldc, int64_t sC, const double* A, int64_t lda, int64_t sA, const double* Bm, int64_t ldb,
                      int64_t sB, int M, int N, int K, int batch) {
   if (M <= 0 || N <= 0 || batch <= 0) return;
-  hipLaunchKernelGGL(k_gemm_f64<SUBTRACT>, dim3((M + 63) / 64, (N + 63) / 64, batch), dim3(256), 0, g_stream, C, ldc, sC, A, lda,
-                     sA, Bm, ldb, sB, M, N, K);
+  hipLaunchKernelGGL((k_gemm_f64<MODE, MA, MB>), dim3((M + 63) / 64, (N + 63) / 64, batch), dim3(256), 0, g_stream, C, ldc, sC, A,
+                     lda, sA, Bm, ldb, sB, M, N, K);
   launch_check();
 }
 __global__ void k_big_root_update(PlanD P, BatchD B, FrontD F) {
@@ -605,10 +623,13 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
                       int32_t nbc, const double* kval) {
   if (nbc <= 0) return;
   if (nbc > 65535) throw Error(-3, "too many batch members for the big-front path");
-  const int w = F.w, ri = F.ri, rs = F.rs, m = w + ri + rs, r = ri + rs;
-  const int64_t mm = (int64_t)m * m;
+  const int w = F.w, ri = F.ri, rs = F.rs, m = w + ri + rs;
+  const int64_t ld = m, mm = (int64_t)m * m, sA = P.scratch_size, sS = P.factor_size, sT = B.tmp_stride;
+  const int64_t lds = w + ri;
   double* A0 = B.scratch + F.f_off;
-  hipLaunchKernelGGL(k_big_zero, dim3(nblocks(mm, 256, 4096), nbc), dim3(256), 0, g_stream, A0, mm, P.scratch_size); launch_check();
+  double* slab = B.factor + (int64_t)b0 * P.factor_size + F.lp_off;
+  double* Qs = B.factor + (int64_t)b0 * P.factor_size + F.q_off;
+  hipLaunchKernelGGL(k_big_zero, dim3(nblocks(mm, 256, 8192), nbc), dim3(256), 0, g_stream, A0, mm, P.scratch_size); launch_check();
   if (F.ent_end > F.ent_begin) {
     hipLaunchKernelGGL(k_big_entries, dim3(nblocks(F.ent_end - F.ent_begin, 256, 256), nbc), dim3(256), 0, g_stream, P, B, F, b0, kval);
     launch_check();
@@ -619,142 +640,165 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     hipLaunchKernelGGL(k_big_extend_add, dim3(nblocks(rc * rc, 256, 8192), nbc), dim3(256), 0, g_stream, P, B, F, kids[c]);
     launch_check();
   }
-  hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(FT), 0, g_stream, P, B, F, b0); launch_check();
-  if (r > 0) {
-    hipLaunchKernelGGL(k_big_trmm_u, dim3((r + 7) / 8, nbc), dim3(256), (size_t)w * 8 * sizeof(double), g_stream, P, B, F); launch_check();
-    hipLaunchKernelGGL(k_big_trmm_l, dim3((r + 7) / 8, nbc), dim3(256), (size_t)w * 8 * sizeof(double), g_stream, P, B, F); launch_check();
-    // Schur update F22 -= L21 U12
-    gemm_f64<true>(A0 + w + (int64_t)m * w, m, P.scratch_size, A0 + w, m, P.scratch_size, A0 + (int64_t)m * w, m, P.scratch_size, r, r, w, nbc);
-    if (ri > 0) {
-      // solve panels: PL = L21_int L11^{-1}, QU = U11^{-1} U12_int (dense inverse copies in tmp)
-      double* fac = B.factor + (int64_t)b0 * P.factor_size;
-      gemm_f64<false>(fac + F.lp_off + w, w + ri, P.factor_size, A0 + w, m, P.scratch_size, B.tmp, w, B.tmp_stride, ri, w, w, nbc);
-      gemm_f64<false>(fac + F.q_off, w, P.factor_size, B.tmp + (int64_t)w * w, w, B.tmp_stride, A0 + (int64_t)m * w, m, P.scratch_size, w, ri, w, nbc);
-    }
-    if (F.parent < 0 && rs > 0) {
-      hipLaunchKernelGGL(k_big_root_update, dim3(nblocks((int64_t)rs * rs, 256, 8192), nbc), dim3(256), 0, g_stream, P, B, F);
+  // ---- blocked right-looking LU of the pivot block, in place, pieces of PIECE columns
+  const int np = (w + PIECE - 1) / PIECE;
+  for (int k = 0; k < np; k++) {
+    const int off = k * PIECE, wk = std::min(PIECE, w - off), rk = m - off - wk;
+    double* Ak = A0 + off * (ld + 1);
+    double* tk = B.tmp + (int64_t)k * 2 * PIECE * PIECE;
+    hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(FT), 0, g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
+    launch_check();
+    if (rk > 0) {
+      hipLaunchKernelGGL(k_big_trmm_u, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);
       launch_check();
+      hipLaunchKernelGGL(k_big_trmm_l, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);
+      launch_check();
+      gemm_f64<1, 0, 0>(Ak + wk + ld * wk, ld, sA, Ak + wk, ld, sA, Ak + ld * wk, ld, sA, rk, rk, wk, nbc);
     }
+  }
+  // ---- explicit inverse of the whole pivot block (block columns / rows from the last to the first)
+  double* T = B.tmp + (int64_t)np * 2 * PIECE * PIECE;   // (w x PIECE) panel scratch
+  for (int j = np - 2; j >= 0; j--) {
+    const int off = j * PIECE, wj = PIECE, rj = w - off - wj;
+    const double* Lf = B.tmp + (int64_t)j * 2 * PIECE * PIECE;
+    const double* Uf = Lf + (int64_t)PIECE * PIECE;
+    // L^{-1}[J+, j] = - L^{-1}[J+, J+] (L[J+, j] L_jj^{-1})
+    gemm_f64<0, 0, 0>(T, rj, sT, A0 + (off + wj) + ld * off, ld, sA, Lf, wj, sT, rj, wj, wj, nbc);
+    gemm_f64<2, 1, 0>(slab + (off + wj) + lds * off, lds, sS, slab + (off + wj) * (lds + 1), lds, sS, T, rj, sT, rj, wj, rj, nbc);
+    // U^{-1}[j, J+] = - (U_jj^{-1} U[j, J+]) U^{-1}[J+, J+]
+    gemm_f64<0, 0, 0>(T, wj, sT, Uf, wj, sT, A0 + off + ld * (off + wj), ld, sA, wj, rj, wj, nbc);
+    gemm_f64<2, 0, 2>(slab + off + lds * (off + wj), lds, sS, T, wj, sT, slab + (off + wj) * (lds + 1), lds, sS, wj, rj, rj, nbc);
+  }
+  if (ri > 0) {
+    // solve panels: PL = L21_int L^{-1}, QU = U^{-1} U12_int
+    gemm_f64<0, 0, 1>(slab + w, lds, sS, A0 + w, ld, sA, slab, lds, sS, ri, w, w, nbc);
+    gemm_f64<0, 2, 0>(Qs, w, sS, slab, lds, sS, A0 + ld * w, ld, sA, w, ri, w, nbc);
+  }
+  if (F.parent < 0 && rs > 0) {
+    hipLaunchKernelGGL(k_big_root_update, dim3(nblocks((int64_t)rs * rs, 256, 8192), nbc), dim3(256), 0, g_stream, P, B, F);
+    launch_check();
   }
 }
 
-// forward sweep of one big front: every workgroup owns 256 rows of [y ; contrib]; it rebuilds the
-// assembled pivot vector t (w entries) and its own rows of the children's contributions in LDS.
-// y goes to the solve workspace first (other workgroups still read x as t), then k_copy_slice.
-__global__ void __launch_bounds__(256) k_solve_fwd_big(PlanD P, BatchD B, FrontD F, const double* __restrict__ x) {
-  extern __shared__ double sh[];   // t[w] | mine[256]
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const int w = F.w, ri = F.ri, rows = w + ri;
+// ---- solves of the big fronts, all big fronts of one tree level per launch
+// assembled vector a = [x pivot slice ; 0] + pulled child contributions, into the workspace
+__global__ void __launch_bounds__(256) k_asm_big(PlanD P, BatchD B, const int32_t* __restrict__ list, const double* __restrict__ x) {
+  const FrontD F = P.fronts[list[blockIdx.y]];
+  const int b = blockIdx.z, rows = F.w + F.ri;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= rows) return;
+  const double* cb = B.contrib + (int64_t)b * P.contrib_size;
+  double v = j < F.w ? x[B.xoff[b] + F.c0 + j] : 0.0;
+  for (int t = P.asm_ptr[F.a_off + j]; t < P.asm_ptr[F.a_off + j + 1]; t++) v += cb[P.asm_src[t]];
+  B.swork[(int64_t)b * B.swork_stride + F.a_off + j] = v;
+}
+// forward: 64 rows per workgroup, the k range split over 8 waves (lane = row, so every panel
+// read is a coalesced 512-byte line and 8 x 64 rows x 4 loads are in flight per workgroup)
+__global__ void __launch_bounds__(512) k_fwd_big(PlanD P, BatchD B, const int32_t* __restrict__ list, double* __restrict__ x) {
+  __shared__ double red[8][64];
+  const FrontD F = P.fronts[list[blockIdx.y]];
+  const int b = blockIdx.z, w = F.w, ri = F.ri, rows = w + ri;
+  const int r0 = blockIdx.x * 64;
+  if (r0 >= rows) return;
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = r0 + lane;
   const int64_t ld = rows;
-  double* t = sh;
-  double* mine = sh + w;
-  const double* xb = x + B.xoff[b];
-  double* cb = B.contrib + (int64_t)b * P.contrib_size;
-  double* yw = B.swork + (int64_t)b * B.swork_stride;
-  const int r0 = blockIdx.x * 256;
-  for (int j = tid; j < w; j += 256) t[j] = xb[F.c0 + j];
-  mine[tid] = 0.0;
-  __syncthreads();
-  for (int ce = F.child_begin; ce < F.child_end; ce++) {
-    const FrontD Cf = P.fronts[P.children[ce]];
-    const int32_t* rel = P.rel + Cf.rel_off;
-    for (int k = tid; k < Cf.ri; k += 256) {
-      const int pos = rel[k];
-      const double v = cb[Cf.c_off + k];
-      if (pos < w) t[pos] += v;                      // positions of one child are unique
-      else if (pos >= r0 && pos < r0 + 256) mine[pos - r0] += v;
-    }
-    __syncthreads();
-  }
-  const int i = r0 + tid;
-  if (i >= rows) return;
-  const double* __restrict__ Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off + i;
-  const int kmax = i < w ? i : w;
+  const double* __restrict__ a = B.swork + (int64_t)b * B.swork_stride + F.a_off;
+  const double* __restrict__ Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off + (i < rows ? i : 0);
+  const int kmax_row = i < w ? i : w;                       // strictly lower part for pivot rows
+  const int kmax = min(w, r0 + 63);                          // bound for the whole chunk
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int k = 0;
-  for (; k + 3 < kmax; k += 4) {
-    a0 += Lp[ld * k] * t[k];
-    a1 += Lp[ld * (k + 1)] * t[k + 1];
-    a2 += Lp[ld * (k + 2)] * t[k + 2];
-    a3 += Lp[ld * (k + 3)] * t[k + 3];
+  int k = g;
+  for (; k + 24 < kmax; k += 32) {
+    const double t0 = a[k], t1 = a[k + 8], t2 = a[k + 16], t3 = a[k + 24];
+    const double l0 = Lp[ld * k], l1 = Lp[ld * (k + 8)], l2 = Lp[ld * (k + 16)], l3 = Lp[ld * (k + 24)];
+    if (i < rows) {
+      if (k < kmax_row) a0 += l0 * t0;
+      if (k + 8 < kmax_row) a1 += l1 * t1;
+      if (k + 16 < kmax_row) a2 += l2 * t2;
+      if (k + 24 < kmax_row) a3 += l3 * t3;
+    }
   }
-  for (; k < kmax; k++) a0 += Lp[ld * k] * t[k];
-  const double sum = (a0 + a1) + (a2 + a3);
-  if (i < w) yw[i] = t[i] + sum;
-  else cb[F.c_off + i - w] = mine[tid] - sum;
+  for (; k < kmax; k += 8)
+    if (i < rows && k < kmax_row) a0 += Lp[ld * k] * a[k];
+  red[g][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && i < rows) {
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) sum += red[q][lane];
+    if (i < w) x[B.xoff[b] + F.c0 + i] = a[i] + sum;
+    else B.contrib[(int64_t)b * P.contrib_size + F.c_off + i - w] = a[i] - sum;
+  }
 }
-__global__ void k_copy_slice(BatchD B, int32_t c0, int32_t w, double* __restrict__ x) {
-  const int b = blockIdx.y;
-  const double* yw = B.swork + (int64_t)b * B.swork_stride;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w; i += gridDim.x * blockDim.x) x[B.xoff[b] + c0 + i] = yw[i];
-}
-void solve_fwd_big(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD*, int32_t, double* x) {
-  if (B.nb <= 0) return;
+void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hf, int32_t count, double* x) {
+  if (count <= 0 || B.nb <= 0) return;
   if (B.nb > 65535) throw Error(-3, "too many batch members for the big-front path");
-  const int rows = F.w + F.ri;
-  hipLaunchKernelGGL(k_solve_fwd_big, dim3((rows + 255) / 256, B.nb), dim3(256), (size_t)(F.w + 256) * sizeof(double), g_stream, P, B, F, x);
-  launch_check();
-  hipLaunchKernelGGL(k_copy_slice, dim3((F.w + 255) / 256, B.nb), dim3(256), 0, g_stream, B, F.c0, F.w, x);
-  launch_check();
+  int maxrows = 0;
+  for (int q = 0; q < count; q++) maxrows = std::max(maxrows, hf[q].w + hf[q].ri);
+  hipLaunchKernelGGL(k_asm_big, dim3((maxrows + 255) / 256, count, B.nb), dim3(256), 0, g_stream, P, B, list, x); launch_check();
+  hipLaunchKernelGGL(k_fwd_big, dim3((maxrows + 63) / 64, count, B.nb), dim3(512), 0, g_stream, P, B, list, x); launch_check();
 }
-// backward sweep of one big front, split over the long k range: partial sums per chunk of 256
-// columns into the workspace, then a fixed-order reduction (bitwise reproducible)
-__global__ void __launch_bounds__(256) k_solve_bwd_big(PlanD P, BatchD B, FrontD F, const double* __restrict__ x) {
-  __shared__ double xs[256];
-  const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
-  const int w = F.w, ri = F.ri;
+// backward: x_s = U^{-1} y_s - (U^{-1} U12) x_ancestors, 64 rows per workgroup, k split over 8 waves;
+// results go to the workspace (other workgroups still read y_s from x), then are copied back
+__global__ void __launch_bounds__(512) k_bwd_big(PlanD P, BatchD B, const int32_t* __restrict__ list, const double* __restrict__ x) {
+  __shared__ double red[8][64];
+  const FrontD F = P.fronts[list[blockIdx.y]];
+  const int b = blockIdx.z, w = F.w, ri = F.ri;
+  const int r0 = blockIdx.x * 64;
+  if (r0 >= w) return;
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = r0 + lane;
   const int64_t ld = w + ri;
   const double* xb = x + B.xoff[b];
   const double* fac = B.factor + (int64_t)b * P.factor_size;
-  double* part = B.swork + (int64_t)b * B.swork_stride + (int64_t)chunk * w;
-  if (chunk == 0) {
-    // pivot block: x_i = sum_{k >= i} Uinv[i,k] y_k ; y staged through LDS in slabs of 256
-    const double* __restrict__ Lp = fac + F.lp_off;
-    for (int i0 = 0; i0 < w; i0 += 256) {
-      const int i = i0 + tid;
-      double s = 0.0;
-      for (int k0 = i0; k0 < w; k0 += 256) {
-        __syncthreads();
-        xs[tid] = (k0 + tid < w) ? xb[F.c0 + k0 + tid] : 0.0;
-        __syncthreads();
-        if (i < w) {
-          const int kb = max(k0, i), ke = min(k0 + 256, w);
-          for (int k = kb; k < ke; k++) s += Lp[i + ld * k] * xs[k - k0];
-        }
-      }
-      if (i < w) part[i] = s;
+  const double* __restrict__ Lp = fac + F.lp_off + (i < w ? i : 0);
+  const double* __restrict__ Q = fac + F.q_off + (i < w ? i : 0);
+  const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+  double a0 = 0.0, a1 = 0.0;
+  // upper triangle of the pivot block: k >= i ; chunk-wide start at r0
+  for (int k = r0 + g; k < w; k += 16) {
+    const double y0 = xb[F.c0 + k];
+    const double l0 = Lp[ld * k];
+    const int k1 = k + 8;
+    const double y1 = k1 < w ? xb[F.c0 + k1] : 0.0;
+    const double l1 = k1 < w ? Lp[ld * k1] : 0.0;
+    if (i < w) {
+      if (k >= i) a0 += l0 * y0;
+      if (k1 >= i) a1 += l1 * y1;
     }
-    return;
   }
-  const int k0 = (chunk - 1) * 256, nk = min(256, ri - k0);
-  const int32_t* __restrict__ idx = P.fidx + F.idx_off + w + k0;
-  xs[tid] = tid < nk ? xb[idx[tid]] : 0.0;
+  for (int k = g; k < ri; k += 16) {
+    const double v0 = xb[idx[k]];
+    const double q0 = Q[(int64_t)w * k];
+    const int k1 = k + 8;
+    const double v1 = k1 < ri ? xb[idx[k1]] : 0.0;
+    const double q1 = k1 < ri ? Q[(int64_t)w * k1] : 0.0;
+    a0 -= q0 * v0;
+    a1 -= q1 * v1;
+  }
+  red[g][lane] = a0 + a1;
   __syncthreads();
-  const double* __restrict__ Q = fac + F.q_off + (int64_t)w * k0;
-  for (int i = tid; i < w; i += 256) {
-    double a0 = 0.0, a1 = 0.0;
-    int k = 0;
-    for (; k + 1 < nk; k += 2) { a0 += Q[i + (int64_t)w * k] * xs[k]; a1 += Q[i + (int64_t)w * (k + 1)] * xs[k + 1]; }
-    if (k < nk) a0 += Q[i + (int64_t)w * k] * xs[k];
-    part[i] = -(a0 + a1);
+  if (g == 0 && i < w) {
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) sum += red[q][lane];
+    B.swork[(int64_t)b * B.swork_stride + P.asm_rows + F.c0 + i] = sum;
   }
 }
-__global__ void k_reduce_chunks(BatchD B, int32_t c0, int32_t w, int32_t nchunk, double* __restrict__ x) {
-  const int b = blockIdx.y;
-  const double* part = B.swork + (int64_t)b * B.swork_stride;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w; i += gridDim.x * blockDim.x) {
-    double s = 0.0;
-    for (int c = 0; c < nchunk; c++) s += part[(int64_t)c * w + i];
-    x[B.xoff[b] + c0 + i] = s;
-  }
+__global__ void k_copy_back_big(PlanD P, BatchD B, const int32_t* __restrict__ list, double* __restrict__ x) {
+  const FrontD F = P.fronts[list[blockIdx.y]];
+  const int b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < F.w) x[B.xoff[b] + F.c0 + i] = B.swork[(int64_t)b * B.swork_stride + P.asm_rows + F.c0 + i];
 }
-void solve_bwd_big(const PlanD& P, const BatchD& B, const FrontD& F, double* x) {
-  if (B.nb <= 0) return;
+void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hf, int32_t count, double* x) {
+  if (count <= 0 || B.nb <= 0) return;
   if (B.nb > 65535) throw Error(-3, "too many batch members for the big-front path");
-  const int nchunk = 1 + (F.ri + 255) / 256;
-  if ((int64_t)nchunk * F.w > B.swork_stride) throw Error(-3, "solve workspace too small for a big front");
-  hipLaunchKernelGGL(k_solve_bwd_big, dim3(nchunk, B.nb), dim3(256), 0, g_stream, P, B, F, x); launch_check();
-  hipLaunchKernelGGL(k_reduce_chunks, dim3((F.w + 255) / 256, B.nb), dim3(256), 0, g_stream, B, F.c0, F.w, nchunk, x); launch_check();
+  int maxw = 0;
+  for (int q = 0; q < count; q++) maxw = std::max(maxw, hf[q].w);
+  hipLaunchKernelGGL(k_bwd_big, dim3((maxw + 63) / 64, count, B.nb), dim3(512), 0, g_stream, P, B, list, x); launch_check();
+  hipLaunchKernelGGL(k_copy_back_big, dim3((maxw + 255) / 256, count, B.nb), dim3(256), 0, g_stream, P, B, list, x); launch_check();
 }
 
 // ------------------------------------------------------------------ solves
@@ -767,14 +811,12 @@ __global__ void __launch_bounds__(256) k_solve_fwd(PlanD P, BatchD B, const int3
   const int w = F.w, ri = F.ri, ld = w + ri;
   double* xb = x + B.xoff[b];
   double* cb = B.contrib + (int64_t)b * P.contrib_size;
-  for (int j = tid; j < ld; j += blockDim.x) f[j] = j < w ? xb[F.c0 + j] : 0.0;
-  __syncthreads();
-  for (int ce = F.child_begin; ce < F.child_end; ce++) {
-    const FrontD Cf = P.fronts[P.children[ce]];
-    const int32_t* rel = P.rel + Cf.rel_off;
-    for (int k = tid; k < Cf.ri; k += blockDim.x) f[rel[k]] += cb[Cf.c_off + k];
-    __syncthreads();
+  for (int j = tid; j < ld; j += blockDim.x) {
+    double v = j < w ? xb[F.c0 + j] : 0.0;
+    for (int t = P.asm_ptr[F.a_off + j]; t < P.asm_ptr[F.a_off + j + 1]; t++) v += cb[P.asm_src[t]];
+    f[j] = v;
   }
+  __syncthreads();
   const double* __restrict__ Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off;
   for (int i = tid; i < ld; i += blockDim.x) {
     double s = f[i];

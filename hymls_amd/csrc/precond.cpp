@@ -26,7 +26,7 @@ inline void gid_coord(const Params& p, int32_t gid, int32_t* c) {
 
 constexpr int LEAF_SIZE = 24;
 constexpr int MAX_WIDTH = 256;
-constexpr int MAX_WIDTH_COARSE = 256;
+constexpr int MAX_WIDTH_COARSE = 256;  // wider supernodes take the piece-wise big-front path
 constexpr int LEAF_SIZE_COARSE = 64;
 constexpr int64_t SCRATCH_BUDGET = 1LL << 30;  // doubles (8 GiB) of frontal scratch per pass
 
@@ -70,7 +70,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   std::vector<dev::FrontD> fd(plan.fronts.size());
   for (size_t s = 0; s < fd.size(); s++) {
     const Front& F = plan.fronts[s];
-    fd[s] = dev::FrontD{F.c0, F.w, F.ri, F.rs, F.parent, F.idx_off, F.rel_off, F.c_off,
+    fd[s] = dev::FrontD{F.c0, F.w, F.ri, F.rs, F.parent, F.idx_off, F.rel_off, F.c_off, F.a_off,
                         F.ent_begin, F.ent_end, F.child_begin, F.child_end, F.f_off, F.lp_off, F.q_off};
   }
   auto keep = [&](auto* p) { owned.push_back((void*)p); return p; };
@@ -82,6 +82,9 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   dplan.ent_id = keep(dev::upload(plan.ent_id));
   dplan.ent_pos = keep(dev::upload(plan.ent_pos));
   dplan.ent_w = keep(dev::upload(plan.ent_w));
+  dplan.asm_ptr = keep(dev::upload(plan.asm_ptr));
+  dplan.asm_src = keep(dev::upload(plan.asm_src));
+  dplan.asm_rows = plan.asm_rows;
   dplan.s_ent_begin = plan.s_ent_begin; dplan.s_ent_end = nent;
   dplan.scratch_size = plan.scratch_size; dplan.factor_size = plan.factor_size;
   dplan.contrib_size = plan.contrib_size;
@@ -109,10 +112,16 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   for (auto& L : plan.big_levels) any_big |= !L.empty();
   batch.tmp = nullptr; batch.tmp_stride = 0; batch.swork = nullptr; batch.swork_stride = 0;
   if (any_big) {
-    batch.tmp_stride = 2LL * plan.max_w * plan.max_w;
+    const int64_t np = (plan.max_w + dev::PIECE - 1) / dev::PIECE;
+    batch.tmp_stride = np * 2 * dev::PIECE * dev::PIECE + 2LL * plan.max_w * dev::PIECE;
     batch.tmp = (double*)keep(dev::alloc((size_t)chunk * batch.tmp_stride * sizeof(double)));
-    batch.swork_stride = 2LL * (plan.max_solve_rows + 64) * 64;
+    batch.swork_stride = (int64_t)plan.asm_rows + plan.nI;
     batch.swork = (double*)keep(dev::alloc((size_t)nb * batch.swork_stride * sizeof(double)));
+    for (auto& L : plan.big_levels) {
+      d_big_lists.push_back(keep(dev::upload(L)));
+      h_big_fronts.emplace_back();
+      for (int s : L) h_big_fronts.back().push_back(fd[s]);
+    }
   }
 }
 
@@ -137,13 +146,12 @@ void BatchedLU::solve(double* x) const {
   const int nl = (int)plan.levels.size();
   for (int l = 0; l < nl; l++) {
     dev::solve_fwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
-    for (int s : plan.big_levels[l]) {
-      auto k = kids_of(s);
-      dev::solve_fwd_big(dplan, batch, h_fronts[s], k.data(), (int32_t)k.size(), x);
-    }
+    if (!plan.big_levels[l].empty())
+      dev::solve_fwd_big(dplan, batch, d_big_lists[l], h_big_fronts[l].data(), (int32_t)plan.big_levels[l].size(), x);
   }
   for (int l = nl - 1; l >= 0; l--) {
-    for (int s : plan.big_levels[l]) dev::solve_bwd_big(dplan, batch, h_fronts[s], x);
+    if (!plan.big_levels[l].empty())
+      dev::solve_bwd_big(dplan, batch, d_big_lists[l], h_big_fronts[l].data(), (int32_t)plan.big_levels[l].size(), x);
     dev::solve_bwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
   }
 }

@@ -154,11 +154,8 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   HYMLS_CHECK((int)P.perm.size() == nI, -3, "ordering lost nodes");
   P.iperm.assign(nI, -1);
   for (int i = 0; i < nI; i++) P.iperm[P.perm[i]] = i;
-  // --- cap the supernode width (chains of panels)
-  std::vector<std::pair<int, int>> sn2;
-  for (auto& s : sn)
-    for (int b = s.first; b < s.second; b += max_width) sn2.emplace_back(b, std::min(b + max_width, s.second));
-  sn.swap(sn2);
+  // wide supernodes stay whole (their pivot block is factored piece by piece in place and then
+  // inverted explicitly, so that the solve needs one panel product per supernode)
   const int nf = (int)sn.size();
   ivec sn_of(nI);
   for (int s = 0; s < nf; s++) for (int t = sn[s].first; t < sn[s].second; t++) sn_of[t] = s;
@@ -199,7 +196,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   P.big_levels.assign(nf ? maxlev + 1 : 0, ivec());
   // --- index lists, offsets
   int64_t foff = 0, fac = 0;
-  int32_t coff = 0;
+  int32_t coff = 0, aoff = 0;
   for (int s = 0; s < nf; s++) {
     Front& F = P.fronts[s];
     F.idx_off = (int32_t)P.fidx.size();
@@ -213,13 +210,14 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
     F.lp_off = fac; fac += (int64_t)(F.w + F.ri) * F.w;
     F.q_off = fac; fac += (int64_t)F.w * F.ri;
     F.c_off = coff; coff += F.ri;
+    F.a_off = aoff; aoff += F.w + F.ri;
     P.max_front = std::max<int32_t>(P.max_front, (int32_t)m);
     P.max_w = std::max<int32_t>(P.max_w, F.w);
     {
       // a front whose Schur update is too much work for one workgroup goes to the multi-workgroup path
       const double r = F.ri + F.rs;
       static const double big_flops = std::getenv("HYMLS_MI_BIG_FLOPS") ? std::atof(std::getenv("HYMLS_MI_BIG_FLOPS")) : 2.5e7;
-      F.big = r * r * F.w > big_flops || m > 2048 || (int64_t)(F.w + F.ri) * F.w > big_panel_entries;
+      F.big = r * r * F.w > big_flops || m > 2048 || (int64_t)(F.w + F.ri) * F.w > big_panel_entries || F.w > max_width;
       (F.big ? P.big_levels : P.levels)[F.level].push_back(s);
     }
     P.max_solve_rows = std::max<int32_t>(P.max_solve_rows, F.w + F.ri);
@@ -253,6 +251,24 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
     const Front& F = P.fronts[s];
     if (F.parent >= 0) continue;
     for (int t = 0; t < F.rs; t++) P.rel[F.rel_off + t] = P.fidx[F.idx_off + F.w + t] - nI;
+  }
+  // --- assembly pull lists: for every row of every front's solve vector [pivot | update rows]
+  //     the contribution-vector entries of its children that land there (fixed order)
+  P.asm_rows = aoff;
+  {
+    std::vector<ivec> src((size_t)aoff);
+    for (int p = 0; p < nf; p++) {
+      const Front& Fp = P.fronts[p];
+      for (int e = Fp.child_begin; e < Fp.child_end; e++) {
+        const Front& Fc = P.fronts[P.children[e]];
+        for (int k = 0; k < Fc.ri; k++) src[(size_t)Fp.a_off + P.rel[Fc.rel_off + k]].push_back(Fc.c_off + k);
+      }
+    }
+    P.asm_ptr.assign((size_t)aoff + 1, 0);
+    for (int i = 0; i < aoff; i++) {
+      P.asm_src.insert(P.asm_src.end(), src[i].begin(), src[i].end());
+      P.asm_ptr[i + 1] = (int32_t)P.asm_src.size();
+    }
   }
   // --- matrix entries -> fronts
   struct Ent { int32_t front, id, pos; double w; };

@@ -38,6 +38,7 @@ struct Front {
   int64_t lp_off = 0;         // L-side panel ((w+ri) x w, col-major) in the factor slab
   int64_t q_off = 0;          // U-side panel (w x ri, col-major) in the factor slab
   int32_t c_off = 0;          // contribution vector (ri) in the per-subdomain solve scratch
+  int32_t a_off = 0;          // first row of this front in the assembled-row numbering (w + ri rows)
   int32_t ent_begin = 0, ent_end = 0;  // matrix entries assembled into this front
   int32_t child_begin = 0, child_end = 0;  // into ClassPlan::children
   bool big = false;            // processed by the multi-workgroup kernels
@@ -57,6 +58,8 @@ struct ClassPlan {
   std::vector<ivec> levels;   // front ids per tree level (leaves = 0): fronts handled by one workgroup each
   std::vector<ivec> big_levels;  // per tree level: fronts spread over many workgroups
   int32_t max_w = 0;
+  int32_t asm_rows = 0;       // sum over fronts of (w + ri)
+  ivec asm_ptr, asm_src;      // per assembled row: contribution entries (index into the contrib array) to add
   // matrix entry assembly: sorted by front; S-block entries last (front == nfronts)
   ivec ent_id;                // entry number in the extended CSR
   ivec ent_pos;               // position in the front (row + m*col) or in S (row + nS*col)

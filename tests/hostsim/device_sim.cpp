@@ -141,11 +141,8 @@ static void sim_fwd_front(const PlanD& P, const BatchD& B, const FrontD& F, int 
       double* xb = x + B.xoff[b];
       double* cb = B.contrib + (int64_t)b * P.contrib_size;
       for (int j = 0; j < w; j++) f[j] = xb[F.c0 + j];
-      for (int ce = F.child_begin; ce < F.child_end; ce++) {
-        const FrontD& C = P.fronts[P.children[ce]];
-        const int32_t* rel = P.rel + C.rel_off;
-        for (int k = 0; k < C.ri; k++) f[rel[k]] += cb[C.c_off + k];
-      }
+      for (int j = 0; j < ld; j++)   // assembly pull lists
+        for (int t = P.asm_ptr[F.a_off + j]; t < P.asm_ptr[F.a_off + j + 1]; t++) f[j] += cb[P.asm_src[t]];
       const double* Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off;
       for (int i = 0; i < w; i++) {
         double s = f[i];
@@ -163,8 +160,8 @@ static void sim_fwd_front(const PlanD& P, const BatchD& B, const FrontD& F, int 
 void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
   for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_fwd_front(P, B, P.fronts[list[q]], b, x);
 }
-void solve_fwd_big(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD*, int32_t, double* x) {
-  for (int b = 0; b < B.nb; b++) sim_fwd_front(P, B, F, b, x);
+void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD*, int32_t count, double* x) {
+  for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_fwd_front(P, B, P.fronts[list[q]], b, x);
 }
 
 static void sim_bwd_front(const PlanD& P, const BatchD& B, const FrontD& F, int b, double* x) {
@@ -191,8 +188,8 @@ static void sim_bwd_front(const PlanD& P, const BatchD& B, const FrontD& F, int 
 void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
   for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_bwd_front(P, B, P.fronts[list[q]], b, x);
 }
-void solve_bwd_big(const PlanD& P, const BatchD& B, const FrontD& F, double* x) {
-  for (int b = 0; b < B.nb; b++) sim_bwd_front(P, B, F, b, x);
+void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD*, int32_t count, double* x) {
+  for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_bwd_front(P, B, P.fronts[list[q]], b, x);
 }
 
 void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t, double* x) {

@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py -- Preconditioner ApplyInverse throughput (DoF/s) + achieved HBM GB/s.
+
+Contract (see task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON
+line on rank 0.  A "step" is one ApplyInverse (one right-hand side, device-resident vectors)
+of the HYMLS preconditioner computed for the synthetic GaleriExt Stokes3D Jacobian of
+BASELINE.json configs[1]: Stokes3D 128^3 (8 388 608 DoF), 2-level (XML "Number of Levels" = 1),
+separator length 8.  The 3D Stokes-C problem is partitioned with the reference's "Skew
+Cartesian" partitioner, the only one the reference itself can run 3D Stokes with.
+
+N > 1 (launched through torch.distributed.run): every rank runs the same workload on its own
+GPU (replicas, no exchange step yet -- DESIGN.md section "multi-GPU"); value is the aggregate.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def cpu_baseline(n, sx, levels, seconds_budget=30.0):
+    """Oracle (numpy/scipy restatement of the reference algorithm, kind 'port') timed on the
+    host cores of this box on a bounded sample: the same partitioner / separator length /
+    level count on an n^3 grid, ApplyInverse only."""
+    from oracle import galeri
+    from oracle.partition import Params
+    from oracle.hymls import Preconditioner as OraclePrec
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:  # pragma: no cover
+        threadpool_limits = None
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    try:
+        A = galeri.stokes3d(n, n, n)
+        tv = galeri.create_testvector(A)
+        p = Params(nx=n, ny=n, nz=n, sx=sx, levels=levels, equations="Stokes-C", partitioner="Skew Cartesian").finalize()
+        t0 = time.time()
+        O = OraclePrec(A, p, testvector=tv).compute()
+        t_setup = time.time() - t0
+        b = np.random.default_rng(0).uniform(-1, 1, A.shape[0])
+        O.apply_inverse(b)
+        reps, t0 = 0, time.time()
+        while reps < 3 or (time.time() - t0 < min(10.0, seconds_budget) and reps < 50):
+            O.apply_inverse(b)
+            reps += 1
+        t_apply = (time.time() - t0) / reps
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    return {"value": A.shape[0] / t_apply, "unit": "DoF/s", "cores": 1, "kind": "port",
+            "sample": "oracle (numpy/scipy, SuperLU per subdomain) ApplyInverse on Stokes3D %d^3 = %d DoF, Skew Cartesian sx=%d, "
+                      "Number of Levels=%d; %d applies of %.3f s after a %.1f s setup" % (n, A.shape[0], sx, levels, reps, t_apply, t_setup)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=128, help="grid size per direction")
+    ap.add_argument("--sx", type=int, default=8)
+    ap.add_argument("--levels", type=int, default=1)
+    ap.add_argument("--cpu-n", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (hymls_amd has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import hymls_amd
+    n, sx, levels = args.n, args.sx, args.levels
+    rp, ci, va = hymls_amd.generate_matrix("Stokes-C", n, n, n)
+    tv = hymls_amd.generate_testvector(rp, ci, va)
+    prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": n, "ny": n, "nz": n},
+           "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
+    P = hymls_amd.Preconditioner((rp, ci, va), prm, testVector=tv, device=local_rank)
+    t0 = time.time(); P.Initialize(); t_init = time.time() - t0
+    t0 = time.time(); P.Compute(); t_comp = time.time() - t0
+    N = rp.size - 1
+    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+    b = torch.rand(N, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    x = torch.empty_like(b)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        P.ApplyInverse(b, x)
+    P.set_profiling(True)   # hipEvents on the library's stream, no synchronisation inside the region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        P.ApplyInverse(b, x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    t_phase = [P.last_apply_seconds(i) for i in range(5)]   # averages over the timed steps
+    P.set_profiling(False)
+    assert bool(torch.isfinite(x).all()), "ApplyInverse produced non-finite values"
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        bytes_all = [P.apply_bytes(i) for i in range(6)]
+        # dominant kernel: k_interior_fused (two launches per ApplyInverse).  Algorithmic bytes
+        # per launch = every stored factor-panel entry once (8 B, forward reads L-side, backward
+        # U-side) + the interior vector in and out.
+        lv = P.level_sizes()
+        n1 = lv[0][1] - lv[0][2]
+        bytes_launch = bytes_all[1] / 2.0 + 16.0 * n1
+        t_launch = t_phase[1] / 2.0
+        achieved = bytes_launch / t_launch / 1e9 if t_launch > 0 else None
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_interior_fused.json")
+        if os.path.exists(prof):
+            try:
+                pj = json.load(open(prof))
+                if pj.get("n") == n and pj.get("sx") == sx and pj.get("levels") == levels:
+                    traffic = pj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Preconditioner ApplyInverse DoF/s + achieved HBM GB/s, Stokes3D",
+            "value": N * world * args.steps / elapsed, "unit": "DoF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "GaleriExt Stokes3D %d^3 (a=nx^2,b=1), %d DoF per GPU, HYMLS %d-level (Number of Levels=%d), "
+                                   "Skew Cartesian sx=%d, Block Diagonal, 1 rhs" % (n, N, levels + 1, levels, sx),
+                       "parallelism": "1 GPU" if world == 1 else "%d replicas (one problem per GPU, no exchange)" % world,
+                       "levels": lv, "initialize_s": t_init, "compute_s": t_comp},
+            "hbm_gbps": bytes_all[0] / (elapsed / args.steps) / 1e9,
+            "apply_bytes": {"total": bytes_all[0], "interior_factors": bytes_all[1], "a12_a21": bytes_all[2],
+                            "separator_blocks_ot": bytes_all[3], "coarse": bytes_all[4], "vectors": bytes_all[5]},
+            "phase_ms": {"apply": 1e3 * t_phase[0], "interior_solves(2 launches)": 1e3 * t_phase[1], "spmv": 1e3 * t_phase[2],
+                         "schur": 1e3 * t_phase[3], "coarse": 1e3 * t_phase[4]},
+            "roofline": {"kernel": "k_interior_fused", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
+                         "bytes_per_launch": bytes_launch, "launch_ms": 1e3 * t_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, sx, levels)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

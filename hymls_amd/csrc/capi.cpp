@@ -25,6 +25,8 @@ struct hymls_mi {
   double *d_b = nullptr, *d_x = nullptr;
   int64_t buf_n = 0;
   bool profiling = false;
+  double prof_sum[8] = {0};
+  int prof_cnt[8] = {0};
 };
 
 static double now() {
@@ -256,13 +258,22 @@ double hymls_mi_apply_bytes(const hymls_mi_t* h, int which) {
     default: return st.bytes_factor + st.bytes_spmv + st.bytes_sep + st.bytes_coarse + st.bytes_vec;
   }
 }
-double hymls_mi_last_apply_seconds(const hymls_mi_t* h, int which) {
+double hymls_mi_last_apply_seconds(const hymls_mi_t* hc, int which) {
+  hymls_mi_t* h = const_cast<hymls_mi_t*>(hc);
   if (!h || !h->top || which < 0 || which > 4) return 0;
-  return h->top->phase_seconds[which];
+  // average seconds per ApplyInverse of phase `which` since profiling was switched on
+  try {
+    double sum[8] = {0}; int cnt[8] = {0};
+    dev::profile_collect(sum, cnt);
+    for (int i = 0; i < 8; i++) { h->prof_sum[i] += sum[i]; h->prof_cnt[i] += cnt[i]; }
+  } catch (...) { return 0; }
+  return h->prof_cnt[0] ? h->prof_sum[which] / h->prof_cnt[0] : 0.0;
 }
 int hymls_mi_set_profiling(hymls_mi_t* h, int on) {
   if (!h) return -2;
   h->profiling = on != 0;
+  for (int i = 0; i < 8; i++) { h->prof_sum[i] = 0; h->prof_cnt[i] = 0; }
+  try { double s[8] = {0}; int c[8] = {0}; dev::profile_collect(s, c); } catch (...) {}
   if (h->top) h->top->profiling = h->profiling;
   return 0;
 }

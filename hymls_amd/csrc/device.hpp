@@ -24,6 +24,11 @@ size_t mem_free();
 // event timing on the stream (seconds); ids are small integers
 void timer_start(int id);
 double timer_stop(int id);  // synchronises
+// non-intrusive phase profiling: mark() records an event on the stream (no synchronisation);
+// profile_collect() synchronises once, adds the elapsed seconds of every begin/end pair to
+// sum[phase], counts the pairs in cnt[phase] and clears the log.  phase < 8.
+void mark(int phase, bool begin);
+void profile_collect(double* sum, int* cnt);
 
 template <class T>
 T* upload(const std::vector<T>& v) {

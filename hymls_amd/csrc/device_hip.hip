@@ -86,6 +86,32 @@ double timer_stop(int id) {
   return 1e-3 * ms;
 }
 
+struct MarkRec { int phase; bool begin; hipEvent_t ev; };
+static std::vector<MarkRec> g_marks;
+static std::vector<hipEvent_t> g_pool;
+void mark(int phase, bool begin) {
+  hipEvent_t e;
+  if (!g_pool.empty()) { e = g_pool.back(); g_pool.pop_back(); }
+  else HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipEventRecord(e, g_stream));
+  g_marks.push_back({phase, begin, e});
+}
+void profile_collect(double* sum, int* cnt) {
+  HIP_CHECK(hipStreamSynchronize(g_stream));
+  hipEvent_t open[8] = {};
+  for (auto& m : g_marks) {
+    if (m.begin) open[m.phase] = m.ev;
+    else if (open[m.phase]) {
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, open[m.phase], m.ev));
+      sum[m.phase] += 1e-3 * ms;
+      cnt[m.phase]++;
+    }
+  }
+  for (auto& m : g_marks) g_pool.push_back(m.ev);
+  g_marks.clear();
+}
+
 static inline void launch_check() { HIP_CHECK(hipGetLastError()); }
 static inline int nblocks(int64_t n, int bs, int cap = 1 << 20) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + bs - 1) / bs, cap)); }
 

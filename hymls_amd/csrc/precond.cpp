@@ -706,7 +706,7 @@ void LevelSolver::compute() {
       next_.reset(next_level_);
       next_level_->initialize();
     }
-    next_level_->profiling = profiling;
+    next_level_->profiling = false;  // phases are reported for the top level only
     next_level_->compute();
   } else {
     next_level_ = nullptr;
@@ -728,7 +728,9 @@ void LevelSolver::schur_apply(double* rhs2, double* x2) {
   dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);                       // B' = H rhs
   for (auto& B : blocks_) dev::blocks_apply(B.nb, B.nblk, B.d_binv, B.d_ids, rhs2, x2);
   dev::gather(ng, d_vs_, rhs2, d_vrhs_);
+  if (profiling && level_ == 0) dev::mark(4, true);
   next_->apply_inverse(d_vrhs_, d_vsol_);
+  if (profiling && level_ == 0) dev::mark(4, false);
   dev::scatter(ng, d_vs_, d_vsol_, x2);
   dev::ot_apply(ng, d_gptr_, d_otw_, x2);                         // Y = H Y
 }
@@ -739,27 +741,23 @@ void LevelSolver::apply_inverse(const double* b, double* x) {
   const int n = K_.n;
   double* z1 = d_z_;
   double* z2 = d_z_ + n1_;
-  if (profiling) dev::timer_start(0);
+  if (profiling) dev::mark(0, true);
   dev::gather(n, d_inperm_, b, d_z_);                       // b1, b2
-  if (profiling) dev::timer_start(1);
+  if (profiling) dev::mark(1, true);
   interior_solve(z1);                                       // x1 = A11 \ b1
-  if (profiling) phase_seconds[1] = dev::timer_stop(1);
-  if (profiling) dev::timer_start(2);
+  if (profiling) { dev::mark(1, false); dev::mark(2, true); }
   dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1, z2, -1.0, 1.0);  // b2 - A21 x1
-  if (profiling) phase_seconds[2] = dev::timer_stop(2);
-  if (profiling) dev::timer_start(3);
+  if (profiling) { dev::mark(2, false); dev::mark(3, true); }
   schur_apply(z2, d_t2_);                                   // x2
-  if (profiling) phase_seconds[3] = dev::timer_stop(3);
-  if (profiling) dev::timer_start(2);
+  if (profiling) { dev::mark(3, false); dev::mark(2, true); }
   dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0);  // y1 = A12 x2
-  if (profiling) phase_seconds[2] += dev::timer_stop(2);
-  if (profiling) dev::timer_start(1);
+  if (profiling) { dev::mark(2, false); dev::mark(1, true); }
   interior_solve(d_t1_);                                    // A11 \ y1
-  if (profiling) phase_seconds[1] += dev::timer_stop(1);
+  if (profiling) dev::mark(1, false);
   dev::axpby(n1_, -1.0, d_t1_, 1.0, z1);                    // x1 -= ...
   dev::d2d(z2, d_t2_, (size_t)n2_ * sizeof(double));
   dev::scatter(n, d_inperm_, d_z_, x);
-  if (profiling) phase_seconds[0] = dev::timer_stop(0);
+  if (profiling) dev::mark(0, false);
 }
 
 void LevelSolver::matvec(const double* x, double* y) const {

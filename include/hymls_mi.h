@@ -112,8 +112,10 @@ int64_t hymls_mi_level_num_subdomains(const hymls_mi_t* h, int level);
  * streams; which = 0 total, 1 interior factor panels (both sweeps, both solves),
  * 2 A12+A21, 3 separator blocks + OT, 4 coarse/next levels, 5 vectors. */
 double hymls_mi_apply_bytes(const hymls_mi_t* h, int which);
-/* device seconds spent in the last ApplyInverse, per phase (hipEvent):
- * which = 0 total, 1 interior solves, 2 SpMV, 3 Schur (OT+blocks), 4 coarse. */
+/* average device seconds per ApplyInverse since profiling was switched on, per phase
+ * (hipEvents recorded on the handle's stream, no synchronisation inside the timed region;
+ * this call synchronises): which = 0 whole call, 1 the two interior-solve launches,
+ * 2 both SpMVs, 3 Schur preconditioner (OT + blocks + next level), 4 next level / coarse solve. */
 double hymls_mi_last_apply_seconds(const hymls_mi_t* h, int which);
 /* enable (1) / disable (0) per-phase event timing inside ApplyInverse. */
 int hymls_mi_set_profiling(hymls_mi_t* h, int on);

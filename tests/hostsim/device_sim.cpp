@@ -24,6 +24,16 @@ void sync() {}
 size_t mem_free() { return (size_t)1 << 40; }
 static std::chrono::steady_clock::time_point t0[16];
 void timer_start(int id) { t0[id] = std::chrono::steady_clock::now(); }
+static std::vector<std::pair<int, std::chrono::steady_clock::time_point>> g_log;
+void mark(int phase, bool begin) { g_log.emplace_back(begin ? phase : phase + 8, std::chrono::steady_clock::now()); }
+void profile_collect(double* sum, int* cnt) {
+  std::chrono::steady_clock::time_point open[8];
+  for (auto& e : g_log) {
+    if (e.first < 8) open[e.first] = e.second;
+    else { sum[e.first - 8] += std::chrono::duration<double>(e.second - open[e.first - 8]).count(); cnt[e.first - 8]++; }
+  }
+  g_log.clear();
+}
 double timer_stop(int id) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0[id]).count(); }
 
 void gather(int64_t n, const int32_t* idx, const double* src, double* dst) { for (int64_t i = 0; i < n; i++) dst[i] = src[idx[i]]; }

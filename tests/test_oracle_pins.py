@@ -1,0 +1,186 @@
+"""-m "not gpu": pins the oracle (CPU restatement) against the reference's own fixtures, unit-test
+formulas and integration targets.  Nothing here touches /root/reference at
+run time: the fixtures are the committed files under tests/golden/ (made by make_golden.py)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import galeri, krylov
+from oracle.partition import Params, HierarchicalMap
+from oracle.skew import SkewPartitioner
+from oracle.hymls import Preconditioner
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def canonical_sha(A):
+    A = A.tocsr().copy()
+    A.sum_duplicates()
+    A.sort_indices()
+    h = hashlib.sha256()
+    h.update(np.asarray(A.indptr, dtype=np.int64).tobytes())
+    h.update(np.asarray(A.indices, dtype=np.int64).tobytes())
+    h.update(np.asarray(A.data, dtype=np.float64).tobytes())
+    return h.hexdigest()
+
+
+def test_stokes3d_generator_reproduces_reference_fixture_bit_for_bit():
+    """reference testSuite/unit_tests/GaleriExt_Stokes3D.cpp:19-62 (there: matvec diff <= 1e-14)."""
+    fx = json.load(open(os.path.join(GOLD, "stokes3d_16_fixture.json")))
+    G = galeri.stokes3d(16, 16, 16, a=1.0 / 16, b=1.0 / 256)
+    assert list(G.shape) == fx["shape"] and G.nnz == fx["nnz"]
+    assert canonical_sha(G) == fx["sha256"]
+
+
+def test_cpp_generator_matches_oracle_generator(hostsim_lib):
+    import hymls_amd
+    g = np.load(os.path.join(GOLD, "stokes3d_4.npz"))
+    rp, ci, va = hymls_amd.generate_matrix("Stokes-C", 4, 4, 4, a=0.25, b=1.0 / 16, lib=hostsim_lib)
+    assert np.array_equal(rp, g["indptr"]) and np.array_equal(ci, g["indices"]) and np.array_equal(va, g["data"])
+    for n in (8, 12):
+        rp, ci, va = hymls_amd.generate_matrix("Stokes-C", n, n, n, lib=hostsim_lib)
+        A = galeri.stokes3d(n, n, n)
+        assert abs(sp.csr_matrix((va, ci, rp), shape=A.shape) - A).max() == 0
+        assert np.array_equal(hymls_amd.generate_testvector(rp, ci, va, lib=hostsim_lib), galeri.create_testvector(A))
+        rp, ci, va = hymls_amd.generate_matrix("Laplace", n, n, n, lib=hostsim_lib)
+        assert abs(sp.csr_matrix((va, ci, rp)) - galeri.laplace3d(n, n, n)).max() == 0
+
+
+def _is_group(gsd, nsx, nsy, nsz):
+    g = [1] * 27
+    if (gsd + 1) % nsx == 0:
+        for i in range(2, 27, 3): g[i] = 0
+    if (gsd % (nsx * nsy)) // nsx == nsy - 1:
+        for i in range(3):
+            for j in range(3): g[6 + i + j * 9] = 0
+    if gsd // (nsx * nsy) == nsz - 1:
+        for i in range(18, 27): g[i] = 0
+    if gsd % nsx == 0:
+        for i in range(0, 27, 3): g[i] = 0
+    if (gsd % (nsx * nsy)) // nsx == 0:
+        for i in range(3):
+            for j in range(3): g[i + j * 9] = 0
+    if gsd // (nsx * nsy) == 0:
+        for i in range(9): g[i] = 0
+    return g
+
+
+@pytest.mark.parametrize("nx,ny,nz,sx", [(8, 8, 8, 4), (16, 16, 16, 4), (16, 8, 8, 4), (4, 4, 4, 2), (8, 4, 4, 4)])
+def test_cartesian_stokes3d_groups(nx, ny, nz, sx):
+    """reference testSuite/unit_tests/HYMLS_OverlappingPartitioner.cpp:537-672."""
+    dof, sy, sz = 4, sx, sx
+    h = HierarchicalMap(Params(nx=nx, ny=ny, nz=nz, dof=4, sx=sx, cx=2, variable_types=list("UVWP")).finalize())
+    nsx, nsy, nsz = nx // sx, ny // sy, nz // sz
+    for sd in range(h.nsd):
+        g = _is_group(sd, nsx, nsy, nsz)
+        ng = sum(g) * 3 - 2 + 1 + g[17] + g[23] + g[25] + g[26]
+        assert len(h.groups[sd]) == ng - 1
+        inter = h.interior[sd]
+        if g[14] == 0 and g[16] == 0 and g[22] == 0:
+            assert len(inter) == sx * sy * sz * dof - 1
+        elif ng == 27 * 3 - 2 + 1 + 4:
+            assert len(inter) == (sx - 1) * (sy - 1) * (sz - 1) * dof - 1 + (sx - 1) * (sy - 1) + (sx - 1) * (sz - 1) + (sy - 1) * (sz - 1)
+            tot = len(inter) + sum(len(x[1]) for x in h.groups[sd])
+            assert tot == sx * sy * sz * dof + ((sx + 1) * (sy + 1) + (sx + 1) * sz + sy * sz) * (dof - 1)
+    allg = np.concatenate([h.interior_map(), h.separator_map()])
+    assert np.array_equal(np.sort(allg), np.arange(nx * ny * nz * dof))
+
+
+@pytest.mark.parametrize("nx,ny,nz,sx,sy,sz", [(8, 8, 8, 4, 4, 4), (16, 16, 16, 4, 4, 4), (16, 8, 8, 4, 4, 4),
+                                              (4, 4, 4, 2, 2, 2), (8, 4, 4, 4, 4, 4), (16, 15, 12, 4, 5, 3)])
+def test_cartesian_laplace3d_groups(nx, ny, nz, sx, sy, sz):
+    """reference testSuite/unit_tests/HYMLS_OverlappingPartitioner.cpp:220-338."""
+    h = HierarchicalMap(Params(nx=nx, ny=ny, nz=nz, dof=1, sx=sx, sy=sy, sz=sz, cx=2, variable_types=["V"]).finalize())
+    nsx, nsy, nsz = nx // sx, ny // sy, nz // sz
+    for sd in range(h.nsd):
+        g = _is_group(sd, nsx, nsy, nsz)
+        ng = sum(g)
+        assert len(h.groups[sd]) == ng - 1
+        inter = h.interior[sd]
+        if g[14] == 0 and g[16] == 0 and g[22] == 0:
+            assert len(inter) == sx * sy * sz
+            x0, y0, z0 = (sd % nsx) * sx, ((sd // nsx) % nsy) * sy, (sd // (nsx * nsy)) * sz
+            sub = x0 + y0 * nx + z0 * nx * ny
+            exp = [sub + i % sx + ((i // sx) % sy) * nx + i // (sx * sy) * nx * ny for i in range(len(inter))]
+            assert list(inter) == exp
+        elif ng == 27:
+            assert len(inter) == (sx - 1) * (sy - 1) * (sz - 1)
+            assert len(inter) + sum(len(x[1]) for x in h.groups[sd]) == sx * sy * sz + (sx + 1) * (sy + 1) + (sx + 1) * sz + sy * sz
+
+
+def test_skew_partitioner_reference_unit_values():
+    """reference testSuite/unit_tests/HYMLS_SkewCartesianPartitioner.cpp:43-70 (operator()),
+    :274-312 (3DNodes: every gid covered), :425-458 (exactly one separator pressure per subdomain)."""
+    p = Params(nx=8, ny=8, nz=8, sx=4, equations="Stokes-C", partitioner="Skew Cartesian").finalize()
+    part = SkewPartitioner(p)
+    for (x, y, z), sd in {(0, 0, 0): 0, (0, 1, 0): 2, (7, 0, 0): 4, (3, 4, 0): 8, (3, 4, 3): 20, (3, 4, 4): 20,
+                          (0, 0, 4): 12, (7, 7, 7): 21}.items():
+        assert part.subdomain_id(x, y, z) == sd
+    assert part.position(0) == (0, 0, 0)
+    seen = np.zeros(8 * 8 * 8 * 4, dtype=int)
+    for sd in range(part.num_subdomains()):
+        inter, groups = part.get_groups(sd)
+        seen[inter] += 1
+        npn = 0
+        for _, g in groups:
+            seen[g] += 1
+            npn += sum(1 for v in g if v % 4 == 3)
+        assert npn == 1
+    assert (seen > 0).all()
+    # 2D: 8 + 4 + 1 + 1 - 1 = 13 groups around a centre subdomain (HYMLS_OverlappingPartitioner.cpp:958-975)
+    h = HierarchicalMap(Params(nx=16, ny=16, nz=1, dim=2, sx=4, cx=2, dof=3, variable_types=list("UVP"),
+                               partitioner="Skew Cartesian").finalize())
+    assert max(len(g) for g in h.groups) == 13
+
+
+def test_exact_inverse_levels0_diagonal_matrix():
+    """reference testSuite/unit_tests/HYMLS_Preconditioner.cpp:247-276 (8x4x4, dof 4, sx 4, levels 0)."""
+    rng = np.random.default_rng(0)
+    n = 8 * 4 * 4 * 4
+    K = sp.diags(rng.uniform(0.0, 1.0, n)).tocsr()
+    P = Preconditioner(K, Params(nx=8, ny=4, nz=4, dof=4, sx=4, levels=0, variable_types=["V"] * 4).finalize()).compute()
+    x = rng.uniform(-1, 1, (n, 2))
+    for k in range(2):
+        assert np.abs(P.apply_inverse(K @ x[:, k]) - x[:, k]).max() < 1e-10
+
+
+def test_threeD1_laplace_cg_iterations():
+    """reference testSuite/integration_tests/threeD1.xml: 3D Laplace 32^3, Cartesian sx=4, Number of Levels=2,
+    CG tol 1e-10, random initial vector: <= 35 iterations, residual and error <= 1e-9."""
+    A = galeri.laplace3d(32, 32, 32)
+    P = Preconditioner(A, Params(nx=32, ny=32, nz=32, sx=4, levels=2, equations="Laplace").finalize(),
+                       testvector=galeri.create_testvector(A)).compute()
+    assert [s[1] for s in P.level_sizes()] == [32768, 2863, 19]
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, A.shape[0]); b = A @ x
+    xs, its, res = krylov.pcg(lambda v: A @ v, b, P.apply_inverse, tol=1e-10, maxit=100, x0=rng.uniform(-1, 1, A.shape[0]))
+    assert its <= 35 and res <= 1e-9 and np.linalg.norm(xs - x) / np.linalg.norm(x) <= 1e-9
+
+
+@pytest.mark.parametrize("kw,max_its,tol", [
+    (dict(sx=8, levels=0), 1, 1e-8),                                             # stokes0_3D.xml
+    (dict(sx=4, cx=2, levels=2, link_velocities=False), 145, 1e-5),              # stokes2_3D.xml
+])
+def test_stokes3d_integration_targets_on_the_reference_fixture(kw, max_its, tol):
+    """reference testSuite/integration_tests/stokes{0,2}_3D.xml on data/DrivenCavity/16x16x16/Re0 (Skew
+    Cartesian, right-preconditioned GMRES 1e-8): iteration / residual / error targets, plus the
+    div-free check of integration_tests.cpp:453-484.  K is regenerated (bit-identical to jac.mtx up to the
+    pressure-column sign convention, see above) and un-flipped; rhs/sol are the reference's files."""
+    g = np.load(os.path.join(GOLD, "drivencavity16_rhs_sol.npz"))
+    rhs, sol = g["rhs"], g["sol"]
+    s = np.ones(16384); s[3::4] = -1.0
+    K = (galeri.stokes3d(16, 16, 16, a=1.0 / 16, b=1.0 / 256) @ sp.diags(s)).tocsr()   # == jac.mtx
+    tv = galeri.create_testvector(K)
+    P = Preconditioner(K, Params(nx=16, ny=16, nz=16, equations="Stokes-C", partitioner="Skew Cartesian", **kw).finalize(),
+                       testvector=tv).compute()
+    xs, its, res = krylov.gmres(lambda v: K @ v, rhs, P.apply_inverse, tol=1e-8, maxit=200)
+    e = xs - sol
+    e[3::4] -= e[3::4].mean()   # pressure is defined up to a constant
+    assert its <= max_its and res <= tol
+    assert np.linalg.norm(e) / np.linalg.norm(sol) <= max(tol, 1e-5)
+    b0 = rhs.copy(); b0[3::4] = 0.0
+    assert np.abs((K @ P.apply_inverse(b0))[3::4]).max() <= 1e-8

@@ -75,7 +75,7 @@ struct BatchD {
   int32_t* flag;         // device int: set != 0 on zero / non-finite pivot
   double* tmp;           // [chunk][tmp_stride] dense pivot-piece inverses + panel scratch (big fronts)
   int64_t tmp_stride;
-  double* swork;         // [nb][swork_stride] solve workspace: assembled rows, then nI outputs
+  double* swork;         // [nb][swork_stride] solve workspace: assembled rows, then partial sums
   int64_t swork_stride;
 };
 
@@ -102,12 +102,16 @@ void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const
 
 // one big front (supernode), spread over many workgroups: its pivot block is factored in pieces
 // of `piece` columns in place, then inverted explicitly (kids: host copies of its children)
-constexpr int PIECE = 256;
+constexpr int PIECE = 128;   // pivot pieces are factored and inverted inside LDS (128 x 128 x 8 B = 128 KiB)
 void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD* kids, int32_t nkids,
                       int32_t b0, int32_t nbc, const double* kval);
 // all big fronts of one tree level (device list of front ids, host copies for the grid sizes)
-void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hfronts, int32_t count, double* x);
-void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hfronts, int32_t count, double* x);
+// poff: device array (per listed front) of offsets into the partial-sum area of the workspace
+constexpr int SOLVE_KT = 1024;   // columns per workgroup tile of the big-front panel products
+void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hfronts, const int64_t* poff,
+                   int32_t count, double* x);
+void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hfronts, const int64_t* poff,
+                   int32_t count, double* x);
 
 // ---- solves with the factor panels; x is the level vector (interior part), in place
 void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x);

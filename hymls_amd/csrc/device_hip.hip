@@ -298,40 +298,85 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     }
     __syncthreads();
   }
-  // 2. LU (no pivoting) of the w x w pivot block
-  for (int k = 0; k < w; k++) {
-    const double piv = A[k + (int64_t)m * k];
-    if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
-    const double ip = 1.0 / piv;
-    __syncthreads();
-    for (int i = k + 1 + tid; i < w; i += FT) A[i + (int64_t)m * k] *= ip;
-    __syncthreads();
-    const int rem = w - k - 1;
-    for (int t = tid; t < rem * rem; t += FT) {
-      const int i = k + 1 + t % rem, j = k + 1 + t / rem;
-      A[i + (int64_t)m * j] -= A[i + (int64_t)m * k] * A[k + (int64_t)m * j];
-    }
-    __syncthreads();
-  }
-  if (s_bad && tid == 0) atomicExch(B.flag, 1);
-  // 3. triangular inverses into the factor slab: strictly lower = L11^{-1}, upper = U11^{-1}
   double* fac = B.factor + (int64_t)b * P.factor_size;
   double* Lp = fac + F.lp_off;
   double* Q = fac + F.q_off;
   const int64_t ld = w + ri;
-  for (int t = tid; t < w; t += FT) {
-    for (int i = t + 1; i < w; i++) {
-      double s = A[i + (int64_t)m * t];
-      for (int j = t + 1; j < i; j++) s += A[i + (int64_t)m * j] * Lp[j + ld * t];
-      Lp[i + ld * t] = -s;
+  if (w * w + w <= STAGE_DOUBLES + 2 * GEMM_KB * 64) {
+    // 2+3 (LDS path): LU of the pivot block and in-place triangular inverses inside LDS
+    double* S = lds;
+    double* xv = lds + w * w;
+    for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + (int64_t)m * (t / w)];
+    __syncthreads();
+    for (int k = 0; k < w; k++) {
+      const double piv = S[k + w * k];
+      if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
+      const double ip = 1.0 / piv;
+      __syncthreads();
+      for (int i = k + 1 + tid; i < w; i += FT) S[i + w * k] *= ip;
+      __syncthreads();
+      const int rem = w - k - 1;
+      for (int t = tid; t < rem * rem; t += FT) {
+        const int i = k + 1 + t % rem, j = k + 1 + t / rem;
+        S[i + w * j] -= S[i + w * k] * S[k + w * j];
+      }
+      __syncthreads();
     }
-    Lp[t + ld * t] = 1.0 / A[t + (int64_t)m * t];
-    for (int i = t - 1; i >= 0; i--) {
-      double s = 0.0;
-      for (int j = i + 1; j <= t; j++) s += A[i + (int64_t)m * j] * Lp[j + ld * t];
-      Lp[i + ld * t] = -s / A[i + (int64_t)m * i];
+    for (int j = w - 2; j >= 0; j--) {
+      for (int i = j + 1 + tid; i < w; i += FT) xv[i] = S[i + w * j];
+      __syncthreads();
+      for (int i = j + 1 + tid; i < w; i += FT) {
+        double sum = xv[i];
+        for (int k = j + 1; k < i; k++) sum += S[i + w * k] * xv[k];
+        S[i + w * j] = -sum;
+      }
+      __syncthreads();
+    }
+    for (int j = 0; j < w; j++) {
+      for (int i = tid; i < j; i += FT) xv[i] = S[i + w * j];
+      const double d = 1.0 / S[j + w * j];
+      __syncthreads();
+      for (int i = tid; i < j; i += FT) {
+        double sum = 0.0;
+        for (int k = i; k < j; k++) sum += S[i + w * k] * xv[k];
+        S[i + w * j] = -sum * d;
+      }
+      if (tid == 0) S[j + w * j] = d;
+      __syncthreads();
+    }
+    for (int t = tid; t < w * w; t += FT) Lp[(t % w) + ld * (t / w)] = S[t];
+  } else {
+    // 2. LU (no pivoting) of the w x w pivot block in global memory (wide pivot blocks)
+    for (int k = 0; k < w; k++) {
+      const double piv = A[k + (int64_t)m * k];
+      if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
+      const double ip = 1.0 / piv;
+      __syncthreads();
+      for (int i = k + 1 + tid; i < w; i += FT) A[i + (int64_t)m * k] *= ip;
+      __syncthreads();
+      const int rem = w - k - 1;
+      for (int t = tid; t < rem * rem; t += FT) {
+        const int i = k + 1 + t % rem, j = k + 1 + t / rem;
+        A[i + (int64_t)m * j] -= A[i + (int64_t)m * k] * A[k + (int64_t)m * j];
+      }
+      __syncthreads();
+    }
+    // 3. triangular inverses into the factor slab: strictly lower = L11^{-1}, upper = U11^{-1}
+    for (int t = tid; t < w; t += FT) {
+      for (int i = t + 1; i < w; i++) {
+        double s = A[i + (int64_t)m * t];
+        for (int j = t + 1; j < i; j++) s += A[i + (int64_t)m * j] * Lp[j + ld * t];
+        Lp[i + ld * t] = -s;
+      }
+      Lp[t + ld * t] = 1.0 / A[t + (int64_t)m * t];
+      for (int i = t - 1; i >= 0; i--) {
+        double s = 0.0;
+        for (int j = i + 1; j <= t; j++) s += A[i + (int64_t)m * j] * Lp[j + ld * t];
+        Lp[i + ld * t] = -s / A[i + (int64_t)m * i];
+      }
     }
   }
+  if (s_bad && tid == 0) atomicExch(B.flag, 1);
   __threadfence_block();
   __syncthreads();
   if (r > 0) {
@@ -458,56 +503,72 @@ __global__ void k_big_extend_add(PlanD P, BatchD B, FrontD F, FrontD Cf) {
     A[rel[a] + (int64_t)m * rel[bb]] += Ac[(Cf.w + a) + (int64_t)mc * (Cf.w + bb)];
   }
 }
-// LU (no pivoting) of one wk x wk pivot piece at A (leading dimension ld), its triangular inverses
-// packed into the supernode's slab block (strictly lower = L^{-1}, upper = U^{-1}) and as dense
-// copies Lf (unit lower) / Uf (upper) for the panel products.  One workgroup per batch slot.
+// LU (no pivoting) of one wk x wk pivot piece (wk <= PIECE = 128), entirely in LDS, followed by the
+// in-place triangular inversions (unit-lower L and upper U share the block).  Results: packed into
+// the supernode's slab block (strictly lower = L^{-1}, upper = U^{-1}) and as dense copies Lf
+// (unit lower) / Uf (upper) for the panel products.  One workgroup per batch slot.
 __global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64_t ld, int64_t strideA, int wk,
                                                   double* __restrict__ slab0, int64_t lds, int64_t strideS,
                                                   double* __restrict__ tmp0, int64_t strideT, int32_t* flag) {
+  extern __shared__ double S[];          // wk x wk block (column-major) + wk work vector
   __shared__ int s_bad;
-  const int tid = threadIdx.x, slot = blockIdx.x;
+  const int tid = threadIdx.x, slot = blockIdx.x, w = wk;
   double* A = A0 + (int64_t)slot * strideA;
   double* Sb = slab0 + (int64_t)slot * strideS;
   double* Lf = tmp0 + (int64_t)slot * strideT;
   double* Uf = Lf + (int64_t)PIECE * PIECE;
-  const int w = wk;
+  double* xv = S + w * w;
   if (tid == 0) s_bad = 0;
+  for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + ld * (t / w)];
   __syncthreads();
+  // right-looking LU
   for (int k = 0; k < w; k++) {
-    const double piv = A[k + ld * k];
+    const double piv = S[k + w * k];
     if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
     const double ip = 1.0 / piv;
     __syncthreads();
-    for (int i = k + 1 + tid; i < w; i += FT) A[i + ld * k] *= ip;
+    for (int i = k + 1 + tid; i < w; i += FT) S[i + w * k] *= ip;
     __syncthreads();
     const int rem = w - k - 1;
     for (int t = tid; t < rem * rem; t += FT) {
       const int i = k + 1 + t % rem, j = k + 1 + t / rem;
-      A[i + ld * j] -= A[i + ld * k] * A[k + ld * j];
+      S[i + w * j] -= S[i + w * k] * S[k + w * j];
     }
     __syncthreads();
   }
   if (s_bad && tid == 0) atomicExch(flag, 1);
-  for (int t = tid; t < w; t += FT) {
-    for (int i = 0; i < t; i++) Lf[i + (int64_t)w * t] = 0.0;
-    Lf[t + (int64_t)w * t] = 1.0;
-    for (int i = t + 1; i < w; i++) {
-      double s = A[i + ld * t];
-      for (int j = t + 1; j < i; j++) s += A[i + ld * j] * Lf[j + (int64_t)w * t];
-      Lf[i + (int64_t)w * t] = -s;
-      Sb[i + lds * t] = -s;
+  // in-place inverse of the unit lower factor: columns from the last to the first,
+  // X[j+1:, j] = - X[j+1:, j+1:] * L[j+1:, j]   (X[j+1:, j+1:] already holds the inverse)
+  for (int j = w - 2; j >= 0; j--) {
+    for (int i = j + 1 + tid; i < w; i += FT) xv[i] = S[i + w * j];
+    __syncthreads();
+    for (int i = j + 1 + tid; i < w; i += FT) {
+      double sum = xv[i];                                   // unit diagonal of X
+      for (int k = j + 1; k < i; k++) sum += S[i + w * k] * xv[k];
+      S[i + w * j] = -sum;
     }
-    const double d = 1.0 / A[t + ld * t];
-    Uf[t + (int64_t)w * t] = d;
-    Sb[t + lds * t] = d;
-    for (int i = t + 1; i < w; i++) Uf[i + (int64_t)w * t] = 0.0;
-    for (int i = t - 1; i >= 0; i--) {
-      double s = 0.0;
-      for (int j = i + 1; j <= t; j++) s += A[i + ld * j] * Uf[j + (int64_t)w * t];
-      const double v = -s / A[i + ld * i];
-      Uf[i + (int64_t)w * t] = v;
-      Sb[i + lds * t] = v;
+    __syncthreads();
+  }
+  // in-place inverse of the upper factor: columns from the first to the last,
+  // Y[j,j] = 1/U[j,j]; Y[0:j, j] = -Y[0:j, 0:j] * U[0:j, j] * Y[j,j]
+  for (int j = 0; j < w; j++) {
+    for (int i = tid; i < j; i += FT) xv[i] = S[i + w * j];
+    const double d = 1.0 / S[j + w * j];
+    __syncthreads();
+    for (int i = tid; i < j; i += FT) {
+      double sum = 0.0;
+      for (int k = i; k < j; k++) sum += S[i + w * k] * xv[k];
+      S[i + w * j] = -sum * d;
     }
+    if (tid == 0) S[j + w * j] = d;
+    __syncthreads();
+  }
+  for (int t = tid; t < w * w; t += FT) {
+    const int i = t % w, j = t / w;
+    const double v = S[t];
+    Sb[i + lds * j] = v;
+    Lf[i + (int64_t)w * j] = i > j ? v : (i == j ? 1.0 : 0.0);
+    Uf[i + (int64_t)w * j] = i <= j ? v : 0.0;
   }
 }
 // row panel right of a pivot piece: U12 = L^{-1} F12 in place, one workgroup per 8 columns
@@ -648,6 +709,11 @@ __global__ void k_big_root_update(PlanD P, BatchD B, FrontD F) {
 void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD* kids, int32_t nkids, int32_t b0,
                       int32_t nbc, const double* kval) {
   if (nbc <= 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_big_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((PIECE * PIECE + PIECE) * sizeof(double))));
+    attr_set = true;
+  }
   if (nbc > 65535) throw Error(-3, "too many batch members for the big-front path");
   const int w = F.w, ri = F.ri, rs = F.rs, m = w + ri + rs;
   const int64_t ld = m, mm = (int64_t)m * m, sA = P.scratch_size, sS = P.factor_size, sT = B.tmp_stride;
@@ -672,7 +738,7 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     const int off = k * PIECE, wk = std::min(PIECE, w - off), rk = m - off - wk;
     double* Ak = A0 + off * (ld + 1);
     double* tk = B.tmp + (int64_t)k * 2 * PIECE * PIECE;
-    hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(FT), 0, g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
+    hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(FT), (size_t)(wk * wk + wk) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
     launch_check();
     if (rk > 0) {
       hipLaunchKernelGGL(k_big_trmm_u, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);
@@ -718,113 +784,160 @@ __global__ void __launch_bounds__(256) k_asm_big(PlanD P, BatchD B, const int32_
   for (int t = P.asm_ptr[F.a_off + j]; t < P.asm_ptr[F.a_off + j + 1]; t++) v += cb[P.asm_src[t]];
   B.swork[(int64_t)b * B.swork_stride + F.a_off + j] = v;
 }
-// forward: 64 rows per workgroup, the k range split over 8 waves (lane = row, so every panel
-// read is a coalesced 512-byte line and 8 x 64 rows x 4 loads are in flight per workgroup)
-__global__ void __launch_bounds__(512) k_fwd_big(PlanD P, BatchD B, const int32_t* __restrict__ list, double* __restrict__ x) {
-  __shared__ double red[8][64];
-  const FrontD F = P.fronts[list[blockIdx.y]];
-  const int b = blockIdx.z, w = F.w, ri = F.ri, rows = w + ri;
-  const int r0 = blockIdx.x * 64;
-  if (r0 >= rows) return;
+// Panel-times-vector products of the big fronts.  A workgroup (4 waves) owns a tile of 64 rows x
+// KT = 1024 columns; lane = row (every panel load is a coalesced 512-byte line), wave g takes 256
+// of the columns, 8 independent loads in flight per lane.  Partial sums go to the workspace and a
+// finalize kernel adds the column tiles in a fixed order (bitwise reproducible).  Tiles that lie
+// entirely outside the triangular part of the pivot block are skipped by both kernels.
+constexpr int KT = 1024;
+__device__ inline double wave4_reduce_store(double v, double (*red)[64], int g, int lane) {
+  red[g][lane] = v;
+  __syncthreads();
+  return red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+__global__ void __launch_bounds__(256) k_panel_fwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
+                                                    int32_t count) {
+  __shared__ double red[4][64];
+  const int q = blockIdx.z % count, b = blockIdx.z / count;
+  const FrontD F = P.fronts[list[q]];
+  const int w = F.w, rows = F.w + F.ri;
+  const int r0 = blockIdx.x * 64, c0k = blockIdx.y * KT;
+  if (r0 >= rows || c0k >= w) return;
+  const int kchunk = (r0 + 63 < w) ? r0 + 63 : w;      // columns >= kchunk are zero for every row of the chunk
+  if (c0k >= kchunk) return;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = r0 + lane;
   const int64_t ld = rows;
   const double* __restrict__ a = B.swork + (int64_t)b * B.swork_stride + F.a_off;
   const double* __restrict__ Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off + (i < rows ? i : 0);
-  const int kmax_row = i < w ? i : w;                       // strictly lower part for pivot rows
-  const int kmax = min(w, r0 + 63);                          // bound for the whole chunk
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int k = g;
-  for (; k + 24 < kmax; k += 32) {
-    const double t0 = a[k], t1 = a[k + 8], t2 = a[k + 16], t3 = a[k + 24];
-    const double l0 = Lp[ld * k], l1 = Lp[ld * (k + 8)], l2 = Lp[ld * (k + 16)], l3 = Lp[ld * (k + 24)];
-    if (i < rows) {
-      if (k < kmax_row) a0 += l0 * t0;
-      if (k + 8 < kmax_row) a1 += l1 * t1;
-      if (k + 16 < kmax_row) a2 += l2 * t2;
-      if (k + 24 < kmax_row) a3 += l3 * t3;
-    }
-  }
-  for (; k < kmax; k += 8)
-    if (i < rows && k < kmax_row) a0 += Lp[ld * k] * a[k];
-  red[g][lane] = (a0 + a1) + (a2 + a3);
-  __syncthreads();
-  if (g == 0 && i < rows) {
-    double sum = 0.0;
+  const int krow = i < rows ? (i < w ? i : w) : 0;    // this row uses columns k < krow
+  const int kb = c0k + g * 256, ke = min(min(kb + 256, kchunk), c0k + KT);
+  double acc[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) sum += red[q][lane];
-    if (i < w) x[B.xoff[b] + F.c0 + i] = a[i] + sum;
-    else B.contrib[(int64_t)b * P.contrib_size + F.c_off + i - w] = a[i] - sum;
+  for (int u = 0; u < 8; u++) acc[u] = 0.0;
+  int k = kb;
+  for (; k + 7 < ke; k += 8) {
+    double l[8], t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { l[u] = Lp[ld * (k + u)]; t[u] = a[k + u]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) if (k + u < krow) acc[u] += l[u] * t[u];
   }
+  for (; k < ke; k++) if (k < krow) acc[0] += Lp[ld * k] * a[k];
+  const double v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  const double sum = wave4_reduce_store(v, red, g, lane);
+  if (g == 0 && i < rows) B.swork[(int64_t)b * B.swork_stride + P.asm_rows + poff[q] + (int64_t)blockIdx.y * rows + i] = sum;
 }
-void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hf, int32_t count, double* x) {
+__global__ void __launch_bounds__(256) k_final_fwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
+                                                    int32_t count, double* __restrict__ x) {
+  const int q = blockIdx.y % count, b = blockIdx.y / count;
+  const FrontD F = P.fronts[list[q]];
+  const int w = F.w, rows = F.w + F.ri;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  const int r0 = (i / 64) * 64;
+  const int kchunk = (r0 + 63 < w) ? r0 + 63 : w;
+  const double* part = B.swork + (int64_t)b * B.swork_stride + P.asm_rows + poff[q];
+  double sum = 0.0;
+  for (int ct = 0; ct * KT < kchunk; ct++) sum += part[(int64_t)ct * rows + i];
+  const double ai = B.swork[(int64_t)b * B.swork_stride + F.a_off + i];
+  if (i < w) x[B.xoff[b] + F.c0 + i] = ai + sum;
+  else B.contrib[(int64_t)b * P.contrib_size + F.c_off + i - w] = ai - sum;
+}
+void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hf, const int64_t* poff, int32_t count,
+                   double* x) {
   if (count <= 0 || B.nb <= 0) return;
-  if (B.nb > 65535) throw Error(-3, "too many batch members for the big-front path");
-  int maxrows = 0;
-  for (int q = 0; q < count; q++) maxrows = std::max(maxrows, hf[q].w + hf[q].ri);
+  if ((int64_t)count * B.nb > 65535) throw Error(-3, "too many (front, member) pairs for the big-front path");
+  int maxrows = 0, maxw = 0;
+  for (int q = 0; q < count; q++) { maxrows = std::max(maxrows, hf[q].w + hf[q].ri); maxw = std::max(maxw, hf[q].w); }
   hipLaunchKernelGGL(k_asm_big, dim3((maxrows + 255) / 256, count, B.nb), dim3(256), 0, g_stream, P, B, list, x); launch_check();
-  hipLaunchKernelGGL(k_fwd_big, dim3((maxrows + 63) / 64, count, B.nb), dim3(512), 0, g_stream, P, B, list, x); launch_check();
+  hipLaunchKernelGGL(k_panel_fwd, dim3((maxrows + 63) / 64, (maxw + KT - 1) / KT, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count);
+  launch_check();
+  hipLaunchKernelGGL(k_final_fwd, dim3((maxrows + 255) / 256, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+  launch_check();
 }
-// backward: x_s = U^{-1} y_s - (U^{-1} U12) x_ancestors, 64 rows per workgroup, k split over 8 waves;
-// results go to the workspace (other workgroups still read y_s from x), then are copied back
-__global__ void __launch_bounds__(512) k_bwd_big(PlanD P, BatchD B, const int32_t* __restrict__ list, const double* __restrict__ x) {
-  __shared__ double red[8][64];
-  const FrontD F = P.fronts[list[blockIdx.y]];
-  const int b = blockIdx.z, w = F.w, ri = F.ri;
+// backward: x_s = U^{-1} y_s - (U^{-1} U12) x_ancestors; column tiles [0, ctU) run over the upper
+// triangle of the pivot block, the following ones over the U-side panel
+__global__ void __launch_bounds__(256) k_panel_bwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
+                                                    int32_t count, const double* __restrict__ x) {
+  __shared__ double red[4][64];
+  const int q = blockIdx.z % count, b = blockIdx.z / count;
+  const FrontD F = P.fronts[list[q]];
+  const int w = F.w, ri = F.ri;
   const int r0 = blockIdx.x * 64;
   if (r0 >= w) return;
+  const int ctU = (w + KT - 1) / KT, ct = blockIdx.y;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = r0 + lane;
-  const int64_t ld = w + ri;
   const double* xb = x + B.xoff[b];
   const double* fac = B.factor + (int64_t)b * P.factor_size;
-  const double* __restrict__ Lp = fac + F.lp_off + (i < w ? i : 0);
-  const double* __restrict__ Q = fac + F.q_off + (i < w ? i : 0);
-  const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
-  double a0 = 0.0, a1 = 0.0;
-  // upper triangle of the pivot block: k >= i ; chunk-wide start at r0
-  for (int k = r0 + g; k < w; k += 16) {
-    const double y0 = xb[F.c0 + k];
-    const double l0 = Lp[ld * k];
-    const int k1 = k + 8;
-    const double y1 = k1 < w ? xb[F.c0 + k1] : 0.0;
-    const double l1 = k1 < w ? Lp[ld * k1] : 0.0;
-    if (i < w) {
-      if (k >= i) a0 += l0 * y0;
-      if (k1 >= i) a1 += l1 * y1;
-    }
-  }
-  for (int k = g; k < ri; k += 16) {
-    const double v0 = xb[idx[k]];
-    const double q0 = Q[(int64_t)w * k];
-    const int k1 = k + 8;
-    const double v1 = k1 < ri ? xb[idx[k1]] : 0.0;
-    const double q1 = k1 < ri ? Q[(int64_t)w * k1] : 0.0;
-    a0 -= q0 * v0;
-    a1 -= q1 * v1;
-  }
-  red[g][lane] = a0 + a1;
-  __syncthreads();
-  if (g == 0 && i < w) {
-    double sum = 0.0;
+  double acc[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) sum += red[q][lane];
-    B.swork[(int64_t)b * B.swork_stride + P.asm_rows + F.c0 + i] = sum;
+  for (int u = 0; u < 8; u++) acc[u] = 0.0;
+  if (ct < ctU) {
+    const int c0k = ct * KT;
+    if (c0k + KT <= r0) return;                       // tile left of the diagonal: all zero
+    const int64_t ld = w + ri;
+    const double* __restrict__ Lp = fac + F.lp_off + (i < w ? i : 0);
+    const double* __restrict__ y = xb + F.c0;
+    const int kb = max(c0k + g * 256, (r0 / 8) * 8), ke = min(c0k + g * 256 + 256, w);
+    int k = kb;
+    for (; k + 7 < ke; k += 8) {
+      double l[8], t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { l[u] = Lp[ld * (k + u)]; t[u] = y[k + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (k + u >= i && i < w) acc[u] += l[u] * t[u];
+    }
+    for (; k < ke; k++) if (k >= i && i < w) acc[0] += Lp[ld * k] * y[k];
+  } else {
+    const int c0k = (ct - ctU) * KT;
+    if (c0k >= ri) return;
+    const double* __restrict__ Q = fac + F.q_off + (i < w ? i : 0);
+    const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+    const int kb = c0k + g * 256, ke = min(kb + 256, ri);
+    int k = kb;
+    for (; k + 7 < ke; k += 8) {
+      double l[8], t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { l[u] = Q[(int64_t)w * (k + u)]; t[u] = xb[idx[k + u]]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] -= l[u] * t[u];
+    }
+    for (; k < ke; k++) acc[0] -= Q[(int64_t)w * k] * xb[idx[k]];
   }
+  const double v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  const double sum = wave4_reduce_store(v, red, g, lane);
+  if (g == 0 && i < w) B.swork[(int64_t)b * B.swork_stride + P.asm_rows + poff[q] + (int64_t)ct * w + i] = sum;
 }
-__global__ void k_copy_back_big(PlanD P, BatchD B, const int32_t* __restrict__ list, double* __restrict__ x) {
-  const FrontD F = P.fronts[list[blockIdx.y]];
-  const int b = blockIdx.z;
+__global__ void __launch_bounds__(256) k_final_bwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
+                                                    int32_t count, double* __restrict__ x) {
+  const int q = blockIdx.y % count, b = blockIdx.y / count;
+  const FrontD F = P.fronts[list[q]];
+  const int w = F.w, ri = F.ri;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < F.w) x[B.xoff[b] + F.c0 + i] = B.swork[(int64_t)b * B.swork_stride + P.asm_rows + F.c0 + i];
+  if (i >= w) return;
+  const int r0 = (i / 64) * 64;
+  const int ctU = (w + KT - 1) / KT, ctQ = (ri + KT - 1) / KT;
+  const double* part = B.swork + (int64_t)b * B.swork_stride + P.asm_rows + poff[q];
+  double sum = 0.0;
+  for (int ct = 0; ct < ctU; ct++) if (ct * KT + KT > r0) sum += part[(int64_t)ct * w + i];
+  for (int ct = 0; ct < ctQ; ct++) sum += part[(int64_t)(ctU + ct) * w + i];
+  x[B.xoff[b] + F.c0 + i] = sum;
 }
-void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hf, int32_t count, double* x) {
+void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hf, const int64_t* poff, int32_t count,
+                   double* x) {
   if (count <= 0 || B.nb <= 0) return;
-  if (B.nb > 65535) throw Error(-3, "too many batch members for the big-front path");
-  int maxw = 0;
-  for (int q = 0; q < count; q++) maxw = std::max(maxw, hf[q].w);
-  hipLaunchKernelGGL(k_bwd_big, dim3((maxw + 63) / 64, count, B.nb), dim3(512), 0, g_stream, P, B, list, x); launch_check();
-  hipLaunchKernelGGL(k_copy_back_big, dim3((maxw + 255) / 256, count, B.nb), dim3(256), 0, g_stream, P, B, list, x); launch_check();
+  if ((int64_t)count * B.nb > 65535) throw Error(-3, "too many (front, member) pairs for the big-front path");
+  int maxw = 0, maxct = 0;
+  for (int q = 0; q < count; q++) {
+    maxw = std::max(maxw, hf[q].w);
+    maxct = std::max(maxct, (hf[q].w + KT - 1) / KT + (hf[q].ri + KT - 1) / KT);
+  }
+  hipLaunchKernelGGL(k_panel_bwd, dim3((maxw + 63) / 64, maxct, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+  launch_check();
+  hipLaunchKernelGGL(k_final_bwd, dim3((maxw + 255) / 256, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+  launch_check();
 }
 
 // ------------------------------------------------------------------ solves

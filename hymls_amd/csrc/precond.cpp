@@ -115,13 +115,24 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
     const int64_t np = (plan.max_w + dev::PIECE - 1) / dev::PIECE;
     batch.tmp_stride = np * 2 * dev::PIECE * dev::PIECE + 2LL * plan.max_w * dev::PIECE;
     batch.tmp = (double*)keep(dev::alloc((size_t)chunk * batch.tmp_stride * sizeof(double)));
-    batch.swork_stride = (int64_t)plan.asm_rows + plan.nI;
-    batch.swork = (double*)keep(dev::alloc((size_t)nb * batch.swork_stride * sizeof(double)));
+    int64_t part_max = 0;
     for (auto& L : plan.big_levels) {
       d_big_lists.push_back(keep(dev::upload(L)));
       h_big_fronts.emplace_back();
-      for (int s : L) h_big_fronts.back().push_back(fd[s]);
+      std::vector<int64_t> poff;
+      int64_t off = 0;
+      for (int s : L) {
+        h_big_fronts.back().push_back(fd[s]);
+        const int64_t w = fd[s].w, ri = fd[s].ri, kt = dev::SOLVE_KT;
+        const int64_t ctw = (w + kt - 1) / kt, ctr = (ri + kt - 1) / kt;
+        poff.push_back(off);
+        off += std::max(ctw * (w + ri), (ctw + ctr) * w);
+      }
+      part_max = std::max(part_max, off);
+      d_big_poff.push_back(keep(dev::upload(poff)));
     }
+    batch.swork_stride = (int64_t)plan.asm_rows + part_max;
+    batch.swork = (double*)keep(dev::alloc((size_t)nb * batch.swork_stride * sizeof(double)));
   }
 }
 
@@ -147,11 +158,11 @@ void BatchedLU::solve(double* x) const {
   for (int l = 0; l < nl; l++) {
     dev::solve_fwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
     if (!plan.big_levels[l].empty())
-      dev::solve_fwd_big(dplan, batch, d_big_lists[l], h_big_fronts[l].data(), (int32_t)plan.big_levels[l].size(), x);
+      dev::solve_fwd_big(dplan, batch, d_big_lists[l], h_big_fronts[l].data(), d_big_poff[l], (int32_t)plan.big_levels[l].size(), x);
   }
   for (int l = nl - 1; l >= 0; l--) {
     if (!plan.big_levels[l].empty())
-      dev::solve_bwd_big(dplan, batch, d_big_lists[l], h_big_fronts[l].data(), (int32_t)plan.big_levels[l].size(), x);
+      dev::solve_bwd_big(dplan, batch, d_big_lists[l], h_big_fronts[l].data(), d_big_poff[l], (int32_t)plan.big_levels[l].size(), x);
     dev::solve_bwd_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), x);
   }
 }

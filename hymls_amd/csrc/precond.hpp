@@ -31,6 +31,7 @@ struct BatchedLU {
   std::vector<dev::FrontD> h_fronts;  // host copies (grid setup of the big-front kernels)
   std::vector<int32_t*> d_big_lists;  // per tree level: ids of the big fronts
   std::vector<std::vector<dev::FrontD>> h_big_fronts;
+  std::vector<int64_t*> d_big_poff;   // per level: partial-sum offsets of the big fronts
   std::vector<dev::FrontD> kids_of(int s) const;
   std::vector<void*> owned;       // device allocations to free
   int32_t nent = 0;

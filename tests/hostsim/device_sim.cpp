@@ -170,7 +170,7 @@ static void sim_fwd_front(const PlanD& P, const BatchD& B, const FrontD& F, int 
 void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
   for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_fwd_front(P, B, P.fronts[list[q]], b, x);
 }
-void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD*, int32_t count, double* x) {
+void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD*, const int64_t*, int32_t count, double* x) {
   for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_fwd_front(P, B, P.fronts[list[q]], b, x);
 }
 
@@ -198,7 +198,7 @@ static void sim_bwd_front(const PlanD& P, const BatchD& B, const FrontD& F, int 
 void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x) {
   for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_bwd_front(P, B, P.fronts[list[q]], b, x);
 }
-void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD*, int32_t count, double* x) {
+void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD*, const int64_t*, int32_t count, double* x) {
   for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_bwd_front(P, B, P.fronts[list[q]], b, x);
 }
 

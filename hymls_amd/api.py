@@ -42,7 +42,7 @@ def load_library(path=None):
         raise ImportError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). hymls_amd has no CPU fallback." % path)
-    if path == os.path.abspath(LIB_PATH):
+    if path == os.path.abspath(LIB_PATH) and not os.environ.get("HYMLS_MI_NO_TORCH"):
         # PyTorch-ROCm owns device memory/streams in this process: let it bring up its HIP
         # runtime first so that both sides share one libamdhip64.
         try:

@@ -40,7 +40,7 @@ T* upload(const std::vector<T>& v) {
 // ---- device-side plan of one pattern class (POD, arrays live on the device)
 struct FrontD {
   int32_t c0, w, ri, rs;
-  int32_t parent, idx_off, rel_off, c_off, a_off;
+  int32_t parent, idx_off, rel_off, c_off, a_off, lf_off;
   int32_t ent_begin, ent_end, child_begin, child_end;
   int64_t f_off, lp_off, q_off;
 };
@@ -57,6 +57,11 @@ struct PlanD {
   const int32_t* asm_ptr;   // [asm_rows + 1]
   const int32_t* asm_src;
   int32_t asm_rows;
+  const int32_t* fw_ptr;    // [nlev + 1] level-synchronous fused solve: forward work items
+  const int32_t* fw_items;  // front << 16 | row
+  const int32_t* bw_ptr;
+  const int32_t* bw_items;
+  int32_t nlev, max_level_rows;
   int32_t s_ent_begin, s_ent_end;
   int64_t scratch_size, factor_size;
   int32_t contrib_size;
@@ -125,7 +130,7 @@ struct FusedSub {
   int32_t xoff;        // offset of its interior block in the level vector
   int32_t cls;         // index into the PlanD table
 };
-constexpr int FUSED_MAX_ROWS = 1024;   // max w + ri of a front handled by the fused kernel
+constexpr int FUSED_MAX_ITEMS = 2048;  // max work items (rows) of one tree level handled by the fused kernel
 void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, double* x);
 
 // ---- separator-side kernels

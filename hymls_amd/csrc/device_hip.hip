@@ -1037,13 +1037,15 @@ void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32
 }
 
 // ------------------------------------------------------------------ fused interior solve
-// One workgroup per subdomain.  LDS: X[nI] solution, C[contrib_size] contribution vectors,
-// R[FUSED_MAX_ROWS] cross-thread reduction scratch.  Fronts are walked in elimination order;
-// a front's panel ((w+ri) x w, column-major) is read with rows on consecutive lanes, the k range
-// split over KG = 256/RT thread groups so that small fronts still keep many loads in flight.
-// Children push their contribution straight into the parent's rows (X for its pivot columns,
-// C for its update rows): fronts run one after the other inside the workgroup, so there are no
-// write conflicts and the result is bitwise reproducible.
+// One workgroup per subdomain, level-synchronous: all fronts of one tree level are processed
+// together, one work item per row of [pivot | update rows] (forward) or per pivot row (backward),
+// so the many small leaf fronts cost ONE memory round trip per level instead of one per front.
+// LDS: X[nI] solution | C[contrib_size] contribution vectors | F[max_level_rows] assembled
+// vectors of the current level | R[256] reduction scratch.  Assembly is a pull (fixed order),
+// hence no write conflicts and bitwise reproducible results.  A panel ((w+ri) x w, column-major)
+// is read with consecutive rows on consecutive lanes; with few items the k range is split over
+// 2 or 4 thread groups so that small levels still keep many loads in flight.
+constexpr int FUSED_ITEMS_PER_THREAD = FUSED_MAX_ITEMS / 256;
 __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
                                                          double* __restrict__ x) {
   extern __shared__ double lds[];
@@ -1051,126 +1053,167 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
   const PlanD P = plans[S.cls];
   double* X = lds;
   double* C = lds + P.nI;
-  double* R = C + P.contrib_size;
+  double* Fv = C + P.contrib_size;
+  double* R = Fv + P.max_level_rows;
   const int tid = threadIdx.x;
   double* xg = x + S.xoff;
   for (int i = tid; i < P.nI; i += 256) X[i] = xg[i];
-  for (int i = tid; i < P.contrib_size; i += 256) C[i] = 0.0;
   __syncthreads();
   const double* __restrict__ fac = S.fac;
-  // ---------------- forward
-  for (int s = 0; s < P.nfronts; s++) {
-    const FrontD F = P.fronts[s];
-    const int w = F.w, ri = F.ri, rows = w + ri;
-    const int64_t ld = rows;
-    const double* __restrict__ Lp = fac + F.lp_off;
-    int RT = 64;
-    while (RT < rows && RT < 256) RT <<= 1;
-    const int KG = 256 / RT;
-    const int rt = tid % RT, kg = tid / RT;
-    const double* Xs = X + F.c0;
-    if (KG == 1) {
-      // rows on threads (up to 4 rows per thread), whole k range per thread
-      double part[4];
+  // ---------------- forward (leaves to root)
+  for (int lev = 0; lev < P.nlev; lev++) {
+    const int ib = P.fw_ptr[lev], ni = P.fw_ptr[lev + 1] - ib;
+    for (int it = tid; it < ni; it += 256) {
+      const int item = P.fw_items[ib + it];
+      const FrontD F = P.fronts[item >> 16];
+      const int r = item & 0xffff;
+      double v = r < F.w ? X[F.c0 + r] : 0.0;
+      for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) v += C[P.asm_src[t]];
+      Fv[F.lf_off + r] = v;
+    }
+    __syncthreads();
+    if (ni > 128) {
+      for (int it = tid; it < ni; it += 256) {
+        const int item = P.fw_items[ib + it];
+        const FrontD F = P.fronts[item >> 16];
+        const int r = item & 0xffff, w = F.w;
+        const int64_t ld = F.w + F.ri;
+        const double* __restrict__ p = fac + F.lp_off + r;
+        const double* f = Fv + F.lf_off;
+        const int kmax = r < w ? r : w;
+        double a[8];
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int i = tid + rr * 256;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        if (i < rows) {
-          const int kmax = i < w ? i : w;
-          const double* p = Lp + i;
-          int k = 0;
-          for (; k + 3 < kmax; k += 4) {
-            a0 += p[ld * k] * Xs[k];
-            a1 += p[ld * (k + 1)] * Xs[k + 1];
-            a2 += p[ld * (k + 2)] * Xs[k + 2];
-            a3 += p[ld * (k + 3)] * Xs[k + 3];
-          }
-          for (; k < kmax; k++) a0 += p[ld * k] * Xs[k];
-        }
-        part[rr] = (a0 + a1) + (a2 + a3);
-      }
-      __syncthreads();   // every read of X[c0..c0+w) is done
-      const int32_t* rel = P.rel + F.rel_off;
+        for (int u = 0; u < 8; u++) a[u] = 0.0;
+        int k = 0;
+        for (; k + 7 < kmax; k += 8) {
+          double l[8];
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int i = tid + rr * 256;
-        if (i < w) X[F.c0 + i] += part[rr];
-        else if (i < rows) {
-          const double c = C[F.c_off + i - w] - part[rr];
-          const FrontD Pa = P.fronts[F.parent];
-          const int pos = rel[i - w];
-          if (pos < Pa.w) X[Pa.c0 + pos] += c; else C[Pa.c_off + pos - Pa.w] += c;
+          for (int u = 0; u < 8; u++) l[u] = p[ld * (k + u)];
+#pragma unroll
+          for (int u = 0; u < 8; u++) a[u] += l[u] * f[k + u];
         }
+        for (; k < kmax; k++) a[0] += p[ld * k] * f[k];
+        const double sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        if (r < w) X[F.c0 + r] = f[r] + sum; else C[F.c_off + r - w] = f[r] - sum;
       }
-      __syncthreads();
     } else {
-      // rows <= 128: RT row-threads x KG k-groups, partial sums combined through LDS
-      double a0 = 0.0, a1 = 0.0;
-      if (rt < rows) {
-        const int kmax = rt < w ? rt : w;
-        const double* p = Lp + rt;
+      const int RT = ni > 64 ? 128 : 64, KG = 256 / RT;
+      const int it = tid % RT, kg = tid / RT;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      if (it < ni) {
+        const int item = P.fw_items[ib + it];
+        const FrontD F = P.fronts[item >> 16];
+        const int r = item & 0xffff, w = F.w;
+        const int64_t ld = F.w + F.ri;
+        const double* __restrict__ p = fac + F.lp_off + r;
+        const double* f = Fv + F.lf_off;
+        const int kmax = r < w ? r : w;
         int k = kg;
-        for (; k + KG < kmax; k += 2 * KG) {
-          a0 += p[ld * k] * Xs[k];
-          a1 += p[ld * (k + KG)] * Xs[k + KG];
+        for (; k + 3 * KG < kmax; k += 4 * KG) {
+          const double l0 = p[ld * k], l1 = p[ld * (k + KG)], l2 = p[ld * (k + 2 * KG)], l3 = p[ld * (k + 3 * KG)];
+          a0 += l0 * f[k]; a1 += l1 * f[k + KG]; a2 += l2 * f[k + 2 * KG]; a3 += l3 * f[k + 3 * KG];
         }
-        if (k < kmax) a0 += p[ld * k] * Xs[k];
+        for (; k < kmax; k += KG) a0 += p[ld * k] * f[k];
       }
-      R[kg * RT + rt] = a0 + a1;
+      R[kg * RT + it] = (a0 + a1) + (a2 + a3);
       __syncthreads();
-      const int32_t* rel = P.rel + F.rel_off;
-      if (tid < rows) {
+      if (tid < ni) {
+        const int item = P.fw_items[ib + tid];
+        const FrontD F = P.fronts[item >> 16];
+        const int r = item & 0xffff;
         double sum = 0.0;
         for (int g = 0; g < KG; g++) sum += R[g * RT + tid];
-        if (tid < w) X[F.c0 + tid] += sum;
-        else {
-          const double c = C[F.c_off + tid - w] - sum;
-          const FrontD Pa = P.fronts[F.parent];
-          const int pos = rel[tid - w];
-          if (pos < Pa.w) X[Pa.c0 + pos] += c; else C[Pa.c_off + pos - Pa.w] += c;
+        const double fr = Fv[F.lf_off + r];
+        if (r < F.w) X[F.c0 + r] = fr + sum; else C[F.c_off + r - F.w] = fr - sum;
+      }
+    }
+    __syncthreads();
+  }
+  // ---------------- backward (root to leaves)
+  for (int lev = P.nlev - 1; lev >= 0; lev--) {
+    const int ib = P.bw_ptr[lev], ni = P.bw_ptr[lev + 1] - ib;
+    double res[FUSED_ITEMS_PER_THREAD];
+    if (ni > 128) {
+#pragma unroll
+      for (int q = 0; q < FUSED_ITEMS_PER_THREAD; q++) {
+        const int it = tid + q * 256;
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = 0.0;
+        if (it < ni) {
+          const int item = P.bw_items[ib + it];
+          const FrontD F = P.fronts[item >> 16];
+          const int i = item & 0xffff, w = F.w, ri = F.ri;
+          const int64_t ld = w + ri;
+          const double* __restrict__ p = fac + F.lp_off + i;
+          const double* Xs = X + F.c0;
+          int k = i;
+          for (; k + 7 < w; k += 8) {
+            double l[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) l[u] = p[ld * (k + u)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] += l[u] * Xs[k + u];
+          }
+          for (; k < w; k++) a[0] += p[ld * k] * Xs[k];
+          const double* __restrict__ qv = fac + F.q_off + i;
+          const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+          k = 0;
+          for (; k + 7 < ri; k += 8) {
+            double l[8]; int id[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { l[u] = qv[(int64_t)w * (k + u)]; id[u] = idx[k + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] -= l[u] * X[id[u]];
+          }
+          for (; k < ri; k++) a[0] -= qv[(int64_t)w * k] * X[idx[k]];
+        }
+        res[q] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      }
+      __syncthreads();   // every read of this level's pivot values is done
+#pragma unroll
+      for (int q = 0; q < FUSED_ITEMS_PER_THREAD; q++) {
+        const int it = tid + q * 256;
+        if (it < ni) {
+          const int item = P.bw_items[ib + it];
+          X[P.fronts[item >> 16].c0 + (item & 0xffff)] = res[q];
         }
       }
+    } else {
+      const int RT = ni > 64 ? 128 : 64, KG = 256 / RT;
+      const int it = tid % RT, kg = tid / RT;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      if (it < ni) {
+        const int item = P.bw_items[ib + it];
+        const FrontD F = P.fronts[item >> 16];
+        const int i = item & 0xffff, w = F.w, ri = F.ri;
+        const int64_t ld = w + ri;
+        const double* __restrict__ p = fac + F.lp_off + i;
+        const double* Xs = X + F.c0;
+        int k = i + kg;
+        for (; k + 3 * KG < w; k += 4 * KG) {
+          const double l0 = p[ld * k], l1 = p[ld * (k + KG)], l2 = p[ld * (k + 2 * KG)], l3 = p[ld * (k + 3 * KG)];
+          a0 += l0 * Xs[k]; a1 += l1 * Xs[k + KG]; a2 += l2 * Xs[k + 2 * KG]; a3 += l3 * Xs[k + 3 * KG];
+        }
+        for (; k < w; k += KG) a0 += p[ld * k] * Xs[k];
+        const double* __restrict__ qv = fac + F.q_off + i;
+        const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+        k = kg;
+        for (; k + 3 * KG < ri; k += 4 * KG) {
+          const double q0 = qv[(int64_t)w * k], q1 = qv[(int64_t)w * (k + KG)], q2 = qv[(int64_t)w * (k + 2 * KG)], q3 = qv[(int64_t)w * (k + 3 * KG)];
+          const int i0 = idx[k], i1 = idx[k + KG], i2 = idx[k + 2 * KG], i3 = idx[k + 3 * KG];
+          a0 -= q0 * X[i0]; a1 -= q1 * X[i1]; a2 -= q2 * X[i2]; a3 -= q3 * X[i3];
+        }
+        for (; k < ri; k += KG) a0 -= qv[(int64_t)w * k] * X[idx[k]];
+      }
+      R[kg * RT + it] = (a0 + a1) + (a2 + a3);
       __syncthreads();
-    }
-  }
-  // ---------------- backward
-  for (int s = P.nfronts - 1; s >= 0; s--) {
-    const FrontD F = P.fronts[s];
-    const int w = F.w, ri = F.ri;
-    const int64_t ld = w + ri;
-    const double* __restrict__ Lp = fac + F.lp_off;
-    const double* __restrict__ Q = fac + F.q_off;
-    const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
-    int RT = 64;
-    while (RT < w && RT < 256) RT <<= 1;
-    const int KG = 256 / RT;
-    const int rt = tid % RT, kg = tid / RT;
-    const double* Xs = X + F.c0;
-    double a0 = 0.0, a1 = 0.0;
-    if (rt < w) {
-      const double* p = Lp + rt;
-      // upper triangle of the pivot block: k >= rt
-      int k = rt + kg;
-      for (; k + KG < w; k += 2 * KG) {
-        a0 += p[ld * k] * Xs[k];
-        a1 += p[ld * (k + KG)] * Xs[k + KG];
+      if (tid < ni) {
+        const int item = P.bw_items[ib + tid];
+        double sum = 0.0;
+        for (int g = 0; g < KG; g++) sum += R[g * RT + tid];
+        X[P.fronts[item >> 16].c0 + (item & 0xffff)] = sum;
       }
-      if (k < w) a0 += p[ld * k] * Xs[k];
-      const double* q = Q + rt;
-      k = kg;
-      for (; k + KG < ri; k += 2 * KG) {
-        a0 -= q[(int64_t)w * k] * X[idx[k]];
-        a1 -= q[(int64_t)w * (k + KG)] * X[idx[k + KG]];
-      }
-      if (k < ri) a0 -= q[(int64_t)w * k] * X[idx[k]];
-    }
-    R[kg * RT + rt] = a0 + a1;
-    __syncthreads();
-    if (tid < w) {
-      double sum = 0.0;
-      for (int g = 0; g < KG; g++) sum += R[g * RT + tid];
-      X[F.c0 + tid] = sum;
     }
     __syncthreads();
   }

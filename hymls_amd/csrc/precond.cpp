@@ -70,7 +70,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   std::vector<dev::FrontD> fd(plan.fronts.size());
   for (size_t s = 0; s < fd.size(); s++) {
     const Front& F = plan.fronts[s];
-    fd[s] = dev::FrontD{F.c0, F.w, F.ri, F.rs, F.parent, F.idx_off, F.rel_off, F.c_off, F.a_off,
+    fd[s] = dev::FrontD{F.c0, F.w, F.ri, F.rs, F.parent, F.idx_off, F.rel_off, F.c_off, F.a_off, F.lf_off,
                         F.ent_begin, F.ent_end, F.child_begin, F.child_end, F.f_off, F.lp_off, F.q_off};
   }
   auto keep = [&](auto* p) { owned.push_back((void*)p); return p; };
@@ -85,6 +85,9 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   dplan.asm_ptr = keep(dev::upload(plan.asm_ptr));
   dplan.asm_src = keep(dev::upload(plan.asm_src));
   dplan.asm_rows = plan.asm_rows;
+  dplan.fw_ptr = keep(dev::upload(plan.fw_ptr)); dplan.fw_items = keep(dev::upload(plan.fw_items));
+  dplan.bw_ptr = keep(dev::upload(plan.bw_ptr)); dplan.bw_items = keep(dev::upload(plan.bw_items));
+  dplan.nlev = (int32_t)plan.levels.size(); dplan.max_level_rows = plan.max_level_rows;
   dplan.s_ent_begin = plan.s_ent_begin; dplan.s_ent_end = nent;
   dplan.scratch_size = plan.scratch_size; dplan.factor_size = plan.factor_size;
   dplan.contrib_size = plan.contrib_size;
@@ -629,10 +632,11 @@ void LevelSolver::build_schur_setup() {
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
     plans.push_back(C.lu.dplan);
-    const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + dev::FUSED_MAX_ROWS;
+    const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + C.lu.plan.max_level_rows + 256;   // X | C | F | R
     bool any_big = false;
     for (auto& L : C.lu.plan.big_levels) any_big |= !L.empty();
-    if (any_big || C.lu.plan.max_solve_rows > dev::FUSED_MAX_ROWS || need > LDS_CAP || C.lu.plan.nI == 0) continue;
+    if (any_big || C.lu.plan.max_level_rows > dev::FUSED_MAX_ITEMS || need > LDS_CAP || C.lu.plan.nI == 0 ||
+        C.lu.plan.fw_items.empty()) continue;
     cls_fused_[c] = 1;
     fused_lds_ = std::max(fused_lds_, need);
     for (size_t b = 0; b < C.lu.members.size(); b++)

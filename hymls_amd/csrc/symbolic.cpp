@@ -270,6 +270,26 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
       P.asm_ptr[i + 1] = (int32_t)P.asm_src.size();
     }
   }
+  // --- work items of the level-synchronous fused solve
+  {
+    const int nl = (int)P.levels.size();
+    P.fw_ptr.assign(1, 0); P.bw_ptr.assign(1, 0);
+    for (int l = 0; l < nl; l++) {
+      int32_t lf = 0;
+      for (int pass = 0; pass < 2; pass++)
+        for (int s : (pass == 0 ? P.levels[l] : P.big_levels[l])) {
+          Front& F = P.fronts[s];
+          F.lf_off = lf; lf += F.w + F.ri;
+          if (nf < 65536 && F.w + F.ri < 65536) {
+            for (int r = 0; r < F.w + F.ri; r++) P.fw_items.push_back((s << 16) | r);
+            for (int r = 0; r < F.w; r++) P.bw_items.push_back((s << 16) | r);
+          }
+        }
+      P.max_level_rows = std::max(P.max_level_rows, lf);
+      P.fw_ptr.push_back((int32_t)P.fw_items.size());
+      P.bw_ptr.push_back((int32_t)P.bw_items.size());
+    }
+  }
   // --- matrix entries -> fronts
   struct Ent { int32_t front, id, pos; double w; };
   std::vector<Ent> ents;

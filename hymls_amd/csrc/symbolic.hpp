@@ -39,6 +39,7 @@ struct Front {
   int64_t q_off = 0;          // U-side panel (w x ri, col-major) in the factor slab
   int32_t c_off = 0;          // contribution vector (ri) in the per-subdomain solve scratch
   int32_t a_off = 0;          // first row of this front in the assembled-row numbering (w + ri rows)
+  int32_t lf_off = 0;         // offset of its assembled vector inside its tree level's LDS region (fused solve)
   int32_t ent_begin = 0, ent_end = 0;  // matrix entries assembled into this front
   int32_t child_begin = 0, child_end = 0;  // into ClassPlan::children
   bool big = false;            // processed by the multi-workgroup kernels
@@ -60,6 +61,10 @@ struct ClassPlan {
   int32_t max_w = 0;
   int32_t asm_rows = 0;       // sum over fronts of (w + ri)
   ivec asm_ptr, asm_src;      // per assembled row: contribution entries (index into the contrib array) to add
+  // level-synchronous fused solve: work items (front << 16 | row) per tree level
+  ivec fw_ptr, fw_items;      // forward: every row of [pivot | update] of every front of the level
+  ivec bw_ptr, bw_items;      // backward: every pivot row of every front of the level
+  int32_t max_level_rows = 0; // max over levels of sum (w + ri)
   // matrix entry assembly: sorted by front; S-block entries last (front == nfronts)
   ivec ent_id;                // entry number in the extended CSR
   ivec ent_pos;               // position in the front (row + m*col) or in S (row + nS*col)

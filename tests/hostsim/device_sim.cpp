@@ -203,44 +203,48 @@ void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const F
 }
 
 void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t, double* x) {
-  std::vector<double> C, acc;
+  // level-synchronous walk with the same work-item tables the HIP kernel uses
+  std::vector<double> C, Fv, out;
   for (int b = 0; b < nsub; b++) {
     const PlanD& P = plans[subs[b].cls];
-    double* xb = x + subs[b].xoff;
+    double* X = x + subs[b].xoff;
     const double* fac = subs[b].fac;
     C.assign(std::max(P.contrib_size, 1), 0.0);
-    for (int s = 0; s < P.nfronts; s++) {  // forward, children push into their parent
-      const FrontD& F = P.fronts[s];
-      const int w = F.w, ri = F.ri, ld = w + ri;
-      const double* Lp = fac + F.lp_off;
-      acc.assign(ld, 0.0);
-      for (int i = 0; i < ld; i++) {
-        double a = 0;
-        const int kmax = i < w ? i : w;
-        for (int k = 0; k < kmax; k++) a += Lp[i + (int64_t)ld * k] * xb[F.c0 + k];
-        acc[i] = a;
+    Fv.assign(std::max(P.max_level_rows, 1), 0.0);
+    for (int lev = 0; lev < P.nlev; lev++) {
+      for (int it = P.fw_ptr[lev]; it < P.fw_ptr[lev + 1]; it++) {
+        const FrontD& F = P.fronts[P.fw_items[it] >> 16];
+        const int r = P.fw_items[it] & 0xffff;
+        double v = r < F.w ? X[F.c0 + r] : 0.0;
+        for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) v += C[P.asm_src[t]];
+        Fv[F.lf_off + r] = v;
       }
-      for (int i = 0; i < w; i++) xb[F.c0 + i] += acc[i];
-      const int32_t* rel = P.rel + F.rel_off;
-      for (int i = 0; i < ri; i++) {
-        const double c = C[F.c_off + i] - acc[w + i];
-        const FrontD& Pa = P.fronts[F.parent];
-        if (rel[i] < Pa.w) xb[Pa.c0 + rel[i]] += c; else C[Pa.c_off + rel[i] - Pa.w] += c;
+      for (int it = P.fw_ptr[lev]; it < P.fw_ptr[lev + 1]; it++) {
+        const FrontD& F = P.fronts[P.fw_items[it] >> 16];
+        const int r = P.fw_items[it] & 0xffff, w = F.w, ld = F.w + F.ri;
+        const double* Lp = fac + F.lp_off;
+        const int kmax = r < w ? r : w;
+        double a = 0;
+        for (int k = 0; k < kmax; k++) a += Lp[r + (int64_t)ld * k] * Fv[F.lf_off + k];
+        if (r < w) X[F.c0 + r] = Fv[F.lf_off + r] + a; else C[F.c_off + r - w] = Fv[F.lf_off + r] - a;
       }
     }
-    for (int s = P.nfronts - 1; s >= 0; s--) {  // backward
-      const FrontD& F = P.fronts[s];
-      const int w = F.w, ri = F.ri, ld = w + ri;
-      const double* Lp = fac + F.lp_off;
-      const double* Q = fac + F.q_off;
-      acc.assign(w, 0.0);
-      for (int i = 0; i < w; i++) {
+    for (int lev = P.nlev - 1; lev >= 0; lev--) {
+      out.assign(P.bw_ptr[lev + 1] - P.bw_ptr[lev], 0.0);
+      for (int it = P.bw_ptr[lev]; it < P.bw_ptr[lev + 1]; it++) {
+        const FrontD& F = P.fronts[P.bw_items[it] >> 16];
+        const int i = P.bw_items[it] & 0xffff, w = F.w, ri = F.ri, ld = w + ri;
+        const double* Lp = fac + F.lp_off;
+        const double* Q = fac + F.q_off;
         double a = 0;
-        for (int k = i; k < w; k++) a += Lp[i + (int64_t)ld * k] * xb[F.c0 + k];
-        for (int k = 0; k < ri; k++) a -= Q[i + (int64_t)w * k] * xb[P.fidx[F.idx_off + w + k]];
-        acc[i] = a;
+        for (int k = i; k < w; k++) a += Lp[i + (int64_t)ld * k] * X[F.c0 + k];
+        for (int k = 0; k < ri; k++) a -= Q[i + (int64_t)w * k] * X[P.fidx[F.idx_off + w + k]];
+        out[it - P.bw_ptr[lev]] = a;
       }
-      for (int i = 0; i < w; i++) xb[F.c0 + i] = acc[i];
+      for (int it = P.bw_ptr[lev]; it < P.bw_ptr[lev + 1]; it++) {
+        const FrontD& F = P.fronts[P.bw_items[it] >> 16];
+        X[F.c0 + (P.bw_items[it] & 0xffff)] = out[it - P.bw_ptr[lev]];
+      }
     }
   }
 }

@@ -1045,7 +1045,6 @@ void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32
 // hence no write conflicts and bitwise reproducible results.  A panel ((w+ri) x w, column-major)
 // is read with consecutive rows on consecutive lanes; with few items the k range is split over
 // 2 or 4 thread groups so that small levels still keep many loads in flight.
-constexpr int FUSED_ITEMS_PER_THREAD = FUSED_MAX_ITEMS / 256;
 __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
                                                          double* __restrict__ x) {
   extern __shared__ double lds[];
@@ -1055,7 +1054,14 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
   double* C = lds + P.nI;
   double* Fv = C + P.contrib_size;
   double* R = Fv + P.max_level_rows;
+  FrontD* LF = (FrontD*)(R + 256);     // all front descriptors of the class, cached in LDS
   const int tid = threadIdx.x;
+  {
+    const int nw = P.nfronts * (int)(sizeof(FrontD) / 4);
+    const int32_t* src = (const int32_t*)P.fronts;
+    int32_t* dst = (int32_t*)LF;
+    for (int i = tid; i < nw; i += 256) dst[i] = src[i];
+  }
   double* xg = x + S.xoff;
   for (int i = tid; i < P.nI; i += 256) X[i] = xg[i];
   __syncthreads();
@@ -1065,7 +1071,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
     const int ib = P.fw_ptr[lev], ni = P.fw_ptr[lev + 1] - ib;
     for (int it = tid; it < ni; it += 256) {
       const int item = P.fw_items[ib + it];
-      const FrontD F = P.fronts[item >> 16];
+      const FrontD& F = LF[item >> 16];
       const int r = item & 0xffff;
       double v = r < F.w ? X[F.c0 + r] : 0.0;
       for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) v += C[P.asm_src[t]];
@@ -1075,25 +1081,25 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
     if (ni > 128) {
       for (int it = tid; it < ni; it += 256) {
         const int item = P.fw_items[ib + it];
-        const FrontD F = P.fronts[item >> 16];
+        const FrontD& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
         const int64_t ld = F.w + F.ri;
         const double* __restrict__ p = fac + F.lp_off + r;
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
-        double a[8];
+        double a[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = 0.0;
+        for (int u = 0; u < 4; u++) a[u] = 0.0;
         int k = 0;
-        for (; k + 7 < kmax; k += 8) {
-          double l[8];
+        for (; k + 3 < kmax; k += 4) {
+          double l[4];
 #pragma unroll
-          for (int u = 0; u < 8; u++) l[u] = p[ld * (k + u)];
+          for (int u = 0; u < 4; u++) l[u] = p[ld * (k + u)];
 #pragma unroll
-          for (int u = 0; u < 8; u++) a[u] += l[u] * f[k + u];
+          for (int u = 0; u < 4; u++) a[u] += l[u] * f[k + u];
         }
         for (; k < kmax; k++) a[0] += p[ld * k] * f[k];
-        const double sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        const double sum = (a[0] + a[1]) + (a[2] + a[3]);
         if (r < w) X[F.c0 + r] = f[r] + sum; else C[F.c_off + r - w] = f[r] - sum;
       }
     } else {
@@ -1102,7 +1108,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       if (it < ni) {
         const int item = P.fw_items[ib + it];
-        const FrontD F = P.fronts[item >> 16];
+        const FrontD& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
         const int64_t ld = F.w + F.ri;
         const double* __restrict__ p = fac + F.lp_off + r;
@@ -1119,7 +1125,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
       __syncthreads();
       if (tid < ni) {
         const int item = P.fw_items[ib + tid];
-        const FrontD F = P.fronts[item >> 16];
+        const FrontD& F = LF[item >> 16];
         const int r = item & 0xffff;
         double sum = 0.0;
         for (int g = 0; g < KG; g++) sum += R[g * RT + tid];
@@ -1132,52 +1138,43 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
   // ---------------- backward (root to leaves)
   for (int lev = P.nlev - 1; lev >= 0; lev--) {
     const int ib = P.bw_ptr[lev], ni = P.bw_ptr[lev + 1] - ib;
-    double res[FUSED_ITEMS_PER_THREAD];
     if (ni > 128) {
+      for (int it = tid; it < ni; it += 256) {
+        const int item = P.bw_items[ib + it];
+        const FrontD& F = LF[item >> 16];
+        const int i = item & 0xffff, w = F.w, ri = F.ri;
+        const int64_t ld = w + ri;
+        const double* __restrict__ p = fac + F.lp_off + i;
+        const double* Xs = X + F.c0;
+        double a[4];
 #pragma unroll
-      for (int q = 0; q < FUSED_ITEMS_PER_THREAD; q++) {
-        const int it = tid + q * 256;
-        double a[8];
+        for (int u = 0; u < 4; u++) a[u] = 0.0;
+        int k = i;
+        for (; k + 3 < w; k += 4) {
+          double l[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = 0.0;
-        if (it < ni) {
-          const int item = P.bw_items[ib + it];
-          const FrontD F = P.fronts[item >> 16];
-          const int i = item & 0xffff, w = F.w, ri = F.ri;
-          const int64_t ld = w + ri;
-          const double* __restrict__ p = fac + F.lp_off + i;
-          const double* Xs = X + F.c0;
-          int k = i;
-          for (; k + 7 < w; k += 8) {
-            double l[8];
+          for (int u = 0; u < 4; u++) l[u] = p[ld * (k + u)];
 #pragma unroll
-            for (int u = 0; u < 8; u++) l[u] = p[ld * (k + u)];
-#pragma unroll
-            for (int u = 0; u < 8; u++) a[u] += l[u] * Xs[k + u];
-          }
-          for (; k < w; k++) a[0] += p[ld * k] * Xs[k];
-          const double* __restrict__ qv = fac + F.q_off + i;
-          const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
-          k = 0;
-          for (; k + 7 < ri; k += 8) {
-            double l[8]; int id[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { l[u] = qv[(int64_t)w * (k + u)]; id[u] = idx[k + u]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) a[u] -= l[u] * X[id[u]];
-          }
-          for (; k < ri; k++) a[0] -= qv[(int64_t)w * k] * X[idx[k]];
+          for (int u = 0; u < 4; u++) a[u] += l[u] * Xs[k + u];
         }
-        res[q] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        for (; k < w; k++) a[0] += p[ld * k] * Xs[k];
+        const double* __restrict__ qv = fac + F.q_off + i;
+        const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+        k = 0;
+        for (; k + 3 < ri; k += 4) {
+          double l[4]; int id[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { l[u] = qv[(int64_t)w * (k + u)]; id[u] = idx[k + u]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) a[u] -= l[u] * X[id[u]];
+        }
+        for (; k < ri; k++) a[0] -= qv[(int64_t)w * k] * X[idx[k]];
+        Fv[it] = (a[0] + a[1]) + (a[2] + a[3]);     // F is free during the backward sweep
       }
       __syncthreads();   // every read of this level's pivot values is done
-#pragma unroll
-      for (int q = 0; q < FUSED_ITEMS_PER_THREAD; q++) {
-        const int it = tid + q * 256;
-        if (it < ni) {
-          const int item = P.bw_items[ib + it];
-          X[P.fronts[item >> 16].c0 + (item & 0xffff)] = res[q];
-        }
+      for (int it = tid; it < ni; it += 256) {
+        const int item = P.bw_items[ib + it];
+        X[LF[item >> 16].c0 + (item & 0xffff)] = Fv[it];
       }
     } else {
       const int RT = ni > 64 ? 128 : 64, KG = 256 / RT;
@@ -1185,7 +1182,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       if (it < ni) {
         const int item = P.bw_items[ib + it];
-        const FrontD F = P.fronts[item >> 16];
+        const FrontD& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
         const int64_t ld = w + ri;
         const double* __restrict__ p = fac + F.lp_off + i;
@@ -1212,7 +1209,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
         const int item = P.bw_items[ib + tid];
         double sum = 0.0;
         for (int g = 0; g < KG; g++) sum += R[g * RT + tid];
-        X[P.fronts[item >> 16].c0 + (item & 0xffff)] = sum;
+        X[LF[item >> 16].c0 + (item & 0xffff)] = sum;
       }
     }
     __syncthreads();

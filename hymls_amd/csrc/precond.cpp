@@ -632,7 +632,8 @@ void LevelSolver::build_schur_setup() {
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
     plans.push_back(C.lu.dplan);
-    const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + C.lu.plan.max_level_rows + 256;   // X | C | F | R
+    const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + C.lu.plan.max_level_rows + 256 +
+                         (int32_t)(C.lu.plan.fronts.size() * sizeof(dev::FrontD) / 8 + 1);   // X | C | F | R | front descriptors
     bool any_big = false;
     for (auto& L : C.lu.plan.big_levels) any_big |= !L.empty();
     if (any_big || C.lu.plan.max_level_rows > dev::FUSED_MAX_ITEMS || need > LDS_CAP || C.lu.plan.nI == 0 ||
@@ -643,6 +644,8 @@ void LevelSolver::build_schur_setup() {
       subs.push_back(dev::FusedSub{C.lu.batch.factor + (int64_t)b * C.lu.plan.factor_size, C.lu.h_xoff[b], (int32_t)c});
   }
   n_fsubs_ = (int32_t)subs.size();
+  if (std::getenv("HYMLS_MI_VERBOSE"))
+    std::fprintf(stderr, "[hymls_mi] level %d: fused interior solve for %d of %zu subdomains, LDS %d doubles (%.1f KiB)\n", level_, n_fsubs_, hm_.sd.size(), fused_lds_, fused_lds_ * 8.0 / 1024);
   d_fplans_ = dev::upload(plans);
   d_fsubs_ = dev::upload(subs);
 }

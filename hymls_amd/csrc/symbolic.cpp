@@ -5,15 +5,28 @@ namespace hymls {
 
 namespace {
 
+constexpr int NDIR = 9;
+const int DIRS[NDIR][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}};
+
 struct NdCtx {
   const std::vector<ivec>* vadj;  // V-graph adjacency (local interior ids)
   const ivec* coord;
   int leaf;
-  std::vector<char> side;                  // scratch marks
+  std::vector<char> side;                  // scratch marks (0 = not in the current set)
+  int reach[NDIR];                          // longest edge of the graph along every direction
   std::vector<std::pair<int, int>> snodes; // (begin, end) into order
   ivec order;                              // V nodes in elimination order
+  inline int proj(int v, int d) const {
+    const ivec& co = *coord;
+    return co[3 * v] * DIRS[d][0] + co[3 * v + 1] * DIRS[d][1] + co[3 * v + 2] * DIRS[d][2];
+  }
 };
 
+// Nested dissection by cutting planes.  Subdomains of the Skew Cartesian partitioner (and the
+// V-sum graphs built on them) have their natural separators on diagonal planes, so the cut is
+// chosen among 9 directions (axes and face diagonals) and a few offsets around the median by the
+// size of the vertex separator it produces (evaluated only inside the slab of nodes an edge can
+// reach across the plane), weighted by the imbalance.
 void nd_recurse(NdCtx& c, ivec& nodes) {
   const int n = (int)nodes.size();
   if (n == 0) return;
@@ -30,51 +43,67 @@ void nd_recurse(NdCtx& c, ivec& nodes) {
     c.snodes.emplace_back(b, (int)c.order.size());
   };
   if (n <= c.leaf) { emit_leaf(nodes); return; }
-  const ivec& co = *c.coord;
-  int lo[3], hi[3];
-  for (int a = 0; a < 3; a++) { lo[a] = INT32_MAX; hi[a] = INT32_MIN; }
-  for (int v : nodes)
-    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], co[3 * v + a]); hi[a] = std::max(hi[a], co[3 * v + a]); }
-  int axes[3] = {0, 1, 2};
-  std::sort(axes, axes + 3, [&](int a, int b) { return (hi[a] - lo[a]) > (hi[b] - lo[b]); });
-  for (int t = 0; t < 3; t++) {
-    const int ax = axes[t];
-    if (hi[ax] == lo[ax]) break;
-    // split value: the coordinate whose "< value" set is closest to half
-    ivec cs(n);
-    for (int i = 0; i < n; i++) cs[i] = co[3 * nodes[i] + ax];
-    std::sort(cs.begin(), cs.end());
-    int best = -1, bestd = n + 1;
+  for (int v : nodes) c.side[v] = 1;   // membership mark while candidates are evaluated
+  const int ntry = n > 50000 ? 1 : (n > 4000 ? 3 : 7);
+  double best_score = 1e300;
+  int best_d = -1, best_t = 0;
+  ivec pr(n), sorted(n);
+  for (int d = 0; d < NDIR; d++) {
+    for (int i = 0; i < n; i++) pr[i] = c.proj(nodes[i], d);
+    sorted = pr;
+    std::sort(sorted.begin(), sorted.end());
+    if (sorted.front() == sorted.back()) continue;
+    // candidate thresholds: distinct values whose "< t" count is closest to n/2
+    std::vector<std::pair<int, int>> cand;  // (|count - n/2|, t)
     for (int i = 1; i < n; i++)
-      if (cs[i] != cs[i - 1]) {  // i = count of coords < cs[i]
-        const int d = std::abs(i - n / 2);
-        if (d < bestd) { bestd = d; best = cs[i]; }
+      if (sorted[i] != sorted[i - 1]) cand.emplace_back(std::abs(i - n / 2), sorted[i]);
+    std::sort(cand.begin(), cand.end());
+    const int nc = std::min<int>(ntry, (int)cand.size());
+    for (int q = 0; q < nc; q++) {
+      const int t = cand[q].second;
+      if (q > 0 && cand[q].first > n / 4) break;   // too unbalanced to be worth it
+      int sepR = 0, sepL = 0, nL = 0;
+      for (int i = 0; i < n; i++) {
+        const int v = nodes[i], pv = pr[i];
+        if (pv < t) nL++;
+        if (pv >= t && pv <= t + c.reach[d]) {
+          for (int u : (*c.vadj)[v]) if (c.side[u] && c.proj(u, d) < t) { sepR++; break; }
+        } else if (pv < t && pv >= t - c.reach[d]) {
+          for (int u : (*c.vadj)[v]) if (c.side[u] && c.proj(u, d) >= t) { sepL++; break; }
+        }
       }
-    if (best == -1) continue;
-    ivec L, R;
-    for (int v : nodes) {
-      if (co[3 * v + ax] < best) { L.push_back(v); c.side[v] = 1; }
-      else { R.push_back(v); c.side[v] = 2; }
+      const int sep = std::min(sepR, sepL);
+      const double imb = std::abs(nL - n / 2) / (double)n;
+      const double score = (sep + 1.0) * (1.0 + 2.0 * imb);
+      if (score < best_score) { best_score = score; best_d = d; best_t = t; }
     }
-    ivec sepR, sepL;
-    for (int v : R)
-      for (int u : (*c.vadj)[v]) if (c.side[u] == 1) { sepR.push_back(v); break; }
-    for (int v : L)
-      for (int u : (*c.vadj)[v]) if (c.side[u] == 2) { sepL.push_back(v); break; }
-    const bool useR = sepR.size() <= sepL.size();
-    ivec& sep = useR ? sepR : sepL;
-    for (int v : sep) c.side[v] = 3;
-    ivec L2, R2;
-    for (int v : L) if (c.side[v] == 1) L2.push_back(v);
-    for (int v : R) if (c.side[v] == 2) R2.push_back(v);
+  }
+  if (best_d < 0) {
     for (int v : nodes) c.side[v] = 0;
-    if (L2.empty() && R2.empty()) { emit_leaf(nodes); return; }
-    nd_recurse(c, L2);
-    nd_recurse(c, R2);
-    if (!sep.empty()) emit_leaf(sep);
+    emit_leaf(nodes);
     return;
   }
-  emit_leaf(nodes);
+  ivec L, R;
+  for (int v : nodes) {
+    if (c.proj(v, best_d) < best_t) { L.push_back(v); c.side[v] = 1; }
+    else { R.push_back(v); c.side[v] = 2; }
+  }
+  ivec sepR, sepL;
+  for (int v : R)
+    for (int u : (*c.vadj)[v]) if (c.side[u] == 1) { sepR.push_back(v); break; }
+  for (int v : L)
+    for (int u : (*c.vadj)[v]) if (c.side[u] == 2) { sepL.push_back(v); break; }
+  const bool useR = sepR.size() <= sepL.size();
+  ivec& sep = useR ? sepR : sepL;
+  for (int v : sep) c.side[v] = 3;
+  ivec L2, R2;
+  for (int v : L) if (c.side[v] == 1) L2.push_back(v);
+  for (int v : R) if (c.side[v] == 2) R2.push_back(v);
+  for (int v : nodes) c.side[v] = 0;
+  if (L2.empty() && R2.empty()) { emit_leaf(nodes); return; }
+  nd_recurse(c, L2);
+  nd_recurse(c, R2);
+  if (!sep.empty()) emit_leaf(sep);
 }
 
 }  // namespace
@@ -116,6 +145,12 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   NdCtx c;
   c.vadj = &vadj; c.coord = &lp.coord; c.leaf = std::max(leaf_size, 1);
   c.side.assign(nI, 0);
+  for (int d = 0; d < NDIR; d++) {
+    int r = 0;
+    for (int v = 0; v < nI; v++)
+      for (int u : vadj[v]) r = std::max(r, std::abs(c.proj(u, d) - c.proj(v, d)));
+    c.reach[d] = r;
+  }
   ivec vnodes;
   for (int i = 0; i < nI; i++) if (!lp.zero_diag[i]) vnodes.push_back(i);
   nd_recurse(c, vnodes);

@@ -44,11 +44,31 @@ void nd_recurse(NdCtx& c, ivec& nodes) {
   };
   if (n <= c.leaf) { emit_leaf(nodes); return; }
   for (int v : nodes) c.side[v] = 1;   // membership mark while candidates are evaluated
-  const int ntry = n > 50000 ? 1 : (n > 4000 ? 3 : 7);
+  const int ntry = n > 4000 ? 9 : 15;
   double best_score = 1e300;
   int best_d = -1, best_t = 0;
   ivec pr(n), sorted(n);
+  // large sets: only the directions whose slab behind the median plane is least populated
+  bool use_dir[NDIR];
+  for (int d = 0; d < NDIR; d++) use_dir[d] = true;
+  if (n > 20000) {
+    std::vector<std::pair<int64_t, int>> pop;
+    for (int d = 0; d < NDIR; d++) {
+      for (int i = 0; i < n; i++) pr[i] = c.proj(nodes[i], d);
+      sorted = pr;
+      std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+      const int med = sorted[n / 2];
+      int64_t cnt = 0;
+      for (int i = 0; i < n; i++) cnt += pr[i] >= med && pr[i] <= med + c.reach[d];
+      pop.emplace_back(cnt, d);
+    }
+    std::sort(pop.begin(), pop.end());
+    for (int d = 0; d < NDIR; d++) use_dir[d] = false;
+    for (int q = 0; q < 3; q++) use_dir[pop[q].second] = true;
+  }
+  ivec mn(n), mx(n);
   for (int d = 0; d < NDIR; d++) {
+    if (!use_dir[d]) continue;
     for (int i = 0; i < n; i++) pr[i] = c.proj(nodes[i], d);
     sorted = pr;
     std::sort(sorted.begin(), sorted.end());
@@ -58,19 +78,27 @@ void nd_recurse(NdCtx& c, ivec& nodes) {
     for (int i = 1; i < n; i++)
       if (sorted[i] != sorted[i - 1]) cand.emplace_back(std::abs(i - n / 2), sorted[i]);
     std::sort(cand.begin(), cand.end());
-    const int nc = std::min<int>(ntry, (int)cand.size());
+    int nc = std::min<int>(ntry, (int)cand.size());
+    while (nc > 1 && cand[nc - 1].first > n / 4) nc--;   // too unbalanced to be worth it
+    int tmin = INT32_MAX, tmax = INT32_MIN;
+    for (int q = 0; q < nc; q++) { tmin = std::min(tmin, cand[q].second); tmax = std::max(tmax, cand[q].second); }
+    // one pass over the slab an edge can reach across any candidate plane: range of the neighbours
+    for (int i = 0; i < n; i++) {
+      const int pv = pr[i];
+      mn[i] = pv; mx[i] = pv;
+      if (pv < tmin - c.reach[d] || pv > tmax + c.reach[d]) continue;
+      int lo = pv, hi = pv;
+      for (int u : (*c.vadj)[nodes[i]])
+        if (c.side[u]) { const int pu = c.proj(u, d); lo = std::min(lo, pu); hi = std::max(hi, pu); }
+      mn[i] = lo; mx[i] = hi;
+    }
     for (int q = 0; q < nc; q++) {
       const int t = cand[q].second;
-      if (q > 0 && cand[q].first > n / 4) break;   // too unbalanced to be worth it
       int sepR = 0, sepL = 0, nL = 0;
       for (int i = 0; i < n; i++) {
-        const int v = nodes[i], pv = pr[i];
-        if (pv < t) nL++;
-        if (pv >= t && pv <= t + c.reach[d]) {
-          for (int u : (*c.vadj)[v]) if (c.side[u] && c.proj(u, d) < t) { sepR++; break; }
-        } else if (pv < t && pv >= t - c.reach[d]) {
-          for (int u : (*c.vadj)[v]) if (c.side[u] && c.proj(u, d) >= t) { sepL++; break; }
-        }
+        const int pv = pr[i];
+        if (pv < t) { nL++; sepL += mx[i] >= t; }
+        else sepR += mn[i] < t;
       }
       const int sep = std::min(sepR, sepL);
       const double imb = std::abs(nL - n / 2) / (double)n;

@@ -63,43 +63,61 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=128, help="grid size per direction")
+    ap.add_argument("--grid", dest="n", type=int, default=128, help="grid size per direction")
     ap.add_argument("--sx", type=int, default=8)
     ap.add_argument("--levels", type=int, default=1)
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--hostsim", action="store_true",
+                    help="TEST ONLY: drive the host-logic simulator on the CPU (tests/test_bench_multirank.py); "
+                         "numbers produced this way are meaningless and are marked as such")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import hymls_amd
+    if args.hostsim:
+        lib = hymls_amd.load_library(os.path.join(ROOT, "tests", "hostsim", "libhymls_mi_hostsim.so"))
+        dev = torch.device("cpu")
+        backend = "gloo"
+    else:
+        lib = None
+        backend = args.backend
+        assert torch.cuda.is_available(), "bench.py needs a GPU (hymls_amd has no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (hymls_amd has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
-    import hymls_amd
     n, sx, levels = args.n, args.sx, args.levels
-    rp, ci, va = hymls_amd.generate_matrix("Stokes-C", n, n, n)
-    tv = hymls_amd.generate_testvector(rp, ci, va)
+    rp, ci, va = hymls_amd.generate_matrix("Stokes-C", n, n, n, lib=lib)
+    tv = hymls_amd.generate_testvector(rp, ci, va, lib=lib)
     prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": n, "ny": n, "nz": n},
            "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
-    P = hymls_amd.Preconditioner((rp, ci, va), prm, testVector=tv, device=local_rank)
+    P = hymls_amd.Preconditioner((rp, ci, va), prm, testVector=tv, device=local_rank, lib=lib)
     t0 = time.time(); P.Initialize(); t_init = time.time() - t0
     t0 = time.time(); P.Compute(); t_comp = time.time() - t0
     N = rp.size - 1
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
     b = torch.rand(N, dtype=torch.float64, device=dev, generator=g) * 2 - 1
     x = torch.empty_like(b)
+    if args.hostsim:   # the simulator works on host memory: hand it numpy views
+        b, x = b.numpy(), x.numpy()
 
     def barrier():
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         P.ApplyInverse(b, x)
@@ -116,7 +134,7 @@ def main():
         elapsed = float(t.item())
     t_phase = [P.last_apply_seconds(i) for i in range(5)]   # averages over the timed steps
     P.set_profiling(False)
-    assert bool(torch.isfinite(x).all()), "ApplyInverse produced non-finite values"
+    assert bool(np.isfinite(x).all() if args.hostsim else torch.isfinite(x).all()), "ApplyInverse produced non-finite values"
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -142,7 +160,8 @@ def main():
             "metric": "Preconditioner ApplyInverse DoF/s + achieved HBM GB/s, Stokes3D",
             "value": N * world * args.steps / elapsed, "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if not args.hostsim else "synthetic (HOST SIMULATOR, TEST ONLY - not a measurement)",
             "config": {"workload": "GaleriExt Stokes3D %d^3 (a=nx^2,b=1), %d DoF per GPU, HYMLS %d-level (Number of Levels=%d), "
                                    "Skew Cartesian sx=%d, Block Diagonal, 1 rhs" % (n, N, levels + 1, levels, sx),
                        "parallelism": "1 GPU" if world == 1 else "%d replicas (one problem per GPU, no exchange)" % world,

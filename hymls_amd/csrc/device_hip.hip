@@ -1045,6 +1045,7 @@ void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32
 // hence no write conflicts and bitwise reproducible results.  A panel ((w+ri) x w, column-major)
 // is read with consecutive rows on consecutive lanes; with few items the k range is split over
 // 2 or 4 thread groups so that small levels still keep many loads in flight.
+struct FusedFront { int32_t c0, w, ri, c_off, a_off, lf_off, idx_off, pad; int64_t lp_off, q_off; };
 __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
                                                          double* __restrict__ x) {
   extern __shared__ double lds[];
@@ -1054,13 +1055,14 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
   double* C = lds + P.nI;
   double* Fv = C + P.contrib_size;
   double* R = Fv + P.max_level_rows;
-  FrontD* LF = (FrontD*)(R + 256);     // all front descriptors of the class, cached in LDS
+  FusedFront* LF = (FusedFront*)(R + 256);     // compact front descriptors of the class, cached in LDS
   const int tid = threadIdx.x;
-  {
-    const int nw = P.nfronts * (int)(sizeof(FrontD) / 4);
-    const int32_t* src = (const int32_t*)P.fronts;
-    int32_t* dst = (int32_t*)LF;
-    for (int i = tid; i < nw; i += 256) dst[i] = src[i];
+  for (int i = tid; i < P.nfronts; i += 256) {
+    const FrontD G = P.fronts[i];
+    FusedFront f;
+    f.c0 = G.c0; f.w = G.w; f.ri = G.ri; f.c_off = G.c_off; f.a_off = G.a_off; f.lf_off = G.lf_off; f.idx_off = G.idx_off; f.pad = 0;
+    f.lp_off = G.lp_off; f.q_off = G.q_off;
+    LF[i] = f;
   }
   double* xg = x + S.xoff;
   for (int i = tid; i < P.nI; i += 256) X[i] = xg[i];
@@ -1071,17 +1073,17 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
     const int ib = P.fw_ptr[lev], ni = P.fw_ptr[lev + 1] - ib;
     for (int it = tid; it < ni; it += 256) {
       const int item = P.fw_items[ib + it];
-      const FrontD& F = LF[item >> 16];
+      const FusedFront& F = LF[item >> 16];
       const int r = item & 0xffff;
       double v = r < F.w ? X[F.c0 + r] : 0.0;
       for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) v += C[P.asm_src[t]];
-      Fv[F.lf_off + r] = v;
+      if (r < F.w) Fv[F.lf_off + r] = v; else C[F.c_off + r - F.w] = v;   // update rows are assembled in place
     }
     __syncthreads();
     if (ni > 128) {
       for (int it = tid; it < ni; it += 256) {
         const int item = P.fw_items[ib + it];
-        const FrontD& F = LF[item >> 16];
+        const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
         const int64_t ld = F.w + F.ri;
         const double* __restrict__ p = fac + F.lp_off + r;
@@ -1100,7 +1102,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
         }
         for (; k < kmax; k++) a[0] += p[ld * k] * f[k];
         const double sum = (a[0] + a[1]) + (a[2] + a[3]);
-        if (r < w) X[F.c0 + r] = f[r] + sum; else C[F.c_off + r - w] = f[r] - sum;
+        if (r < w) X[F.c0 + r] = f[r] + sum; else C[F.c_off + r - w] -= sum;
       }
     } else {
       const int RT = ni > 64 ? 128 : 64, KG = 256 / RT;
@@ -1108,7 +1110,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       if (it < ni) {
         const int item = P.fw_items[ib + it];
-        const FrontD& F = LF[item >> 16];
+        const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
         const int64_t ld = F.w + F.ri;
         const double* __restrict__ p = fac + F.lp_off + r;
@@ -1125,12 +1127,11 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
       __syncthreads();
       if (tid < ni) {
         const int item = P.fw_items[ib + tid];
-        const FrontD& F = LF[item >> 16];
+        const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff;
         double sum = 0.0;
         for (int g = 0; g < KG; g++) sum += R[g * RT + tid];
-        const double fr = Fv[F.lf_off + r];
-        if (r < F.w) X[F.c0 + r] = fr + sum; else C[F.c_off + r - F.w] = fr - sum;
+        if (r < F.w) X[F.c0 + r] = Fv[F.lf_off + r] + sum; else C[F.c_off + r - F.w] -= sum;
       }
     }
     __syncthreads();
@@ -1141,7 +1142,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
     if (ni > 128) {
       for (int it = tid; it < ni; it += 256) {
         const int item = P.bw_items[ib + it];
-        const FrontD& F = LF[item >> 16];
+        const FusedFront& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
         const int64_t ld = w + ri;
         const double* __restrict__ p = fac + F.lp_off + i;
@@ -1182,7 +1183,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       if (it < ni) {
         const int item = P.bw_items[ib + it];
-        const FrontD& F = LF[item >> 16];
+        const FusedFront& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
         const int64_t ld = w + ri;
         const double* __restrict__ p = fac + F.lp_off + i;

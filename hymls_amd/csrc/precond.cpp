@@ -633,7 +633,7 @@ void LevelSolver::build_schur_setup() {
     Cls& C = *cls_[c];
     plans.push_back(C.lu.dplan);
     const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + C.lu.plan.max_level_rows + 256 +
-                         (int32_t)(C.lu.plan.fronts.size() * sizeof(dev::FrontD) / 8 + 1);   // X | C | F | R | front descriptors
+                         (int32_t)(C.lu.plan.fronts.size() * 6 + 1);   // X | C | F | R | compact front descriptors (48 B)
     bool any_big = false;
     for (auto& L : C.lu.plan.big_levels) any_big |= !L.empty();
     if (any_big || C.lu.plan.max_level_rows > dev::FUSED_MAX_ITEMS || need > LDS_CAP || C.lu.plan.nI == 0 ||

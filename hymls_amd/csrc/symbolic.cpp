@@ -139,9 +139,9 @@ void nd_recurse(NdCtx& c, ivec& nodes) {
 void print_plan_stats(const ClassPlan& P, const char* label, int nmembers) {
   int nbig = 0, maxw = 0, maxr = 0;
   for (auto& F : P.fronts) { nbig += F.big; maxw = std::max(maxw, F.w); maxr = std::max(maxr, F.ri + F.rs); }
-  std::fprintf(stderr, "[hymls_mi] %s: members %d nI %d nS %d fronts %zu (big %d) levels %zu max_w %d max_r %d nnz_factor %.3g scratch %.3g MB flops %.3g\n",
+  std::fprintf(stderr, "[hymls_mi] %s: members %d nI %d nS %d fronts %zu (big %d) levels %zu max_w %d max_r %d nnz_factor %.3g scratch %.3g MB flops %.3g contrib %d level_rows %d\n",
                label, nmembers, P.nI, P.nS, P.fronts.size(), nbig, P.levels.size(), maxw, maxr, (double)P.nnz_factor,
-               8e-6 * (double)P.scratch_size, (double)P.flops_factor);
+               8e-6 * (double)P.scratch_size, (double)P.flops_factor, P.contrib_size, P.max_level_rows);
 }
 
 ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, int64_t big_panel_entries) {
@@ -272,7 +272,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
     F.f_off = foff; foff += m * m;
     F.lp_off = fac; fac += (int64_t)(F.w + F.ri) * F.w;
     F.q_off = fac; fac += (int64_t)F.w * F.ri;
-    F.c_off = coff; coff += F.ri;
+    F.c_off = 0;
     F.a_off = aoff; aoff += F.w + F.ri;
     P.max_front = std::max<int32_t>(P.max_front, (int32_t)m);
     P.max_w = std::max<int32_t>(P.max_w, F.w);
@@ -287,6 +287,37 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
     P.nnz_factor += (int64_t)F.w * F.w + 2LL * F.w * F.ri;
     const double w = F.w, r = F.ri + F.rs;
     P.flops_factor += (int64_t)(2.0 / 3.0 * w * w * w + 2.0 * w * w * r + 2.0 * w * r * r);
+  }
+  // contribution vectors: a front's vector is written at its own tree level and read at its parent's;
+  // its space is reused from the level after the parent's (first-fit free list)
+  {
+    const int nl = (int)P.levels.size();
+    std::vector<ivec> by_level(nl), release(nl + 1);
+    for (int s = 0; s < nf; s++) by_level[P.fronts[s].level].push_back(s);
+    std::vector<std::pair<int32_t, int32_t>> freel;  // (offset, size)
+    for (int l = 0; l < nl; l++) {
+      for (int s : release[l]) {
+        freel.emplace_back(P.fronts[s].c_off, P.fronts[s].ri);
+      }
+      // merge adjacent free blocks
+      std::sort(freel.begin(), freel.end());
+      std::vector<std::pair<int32_t, int32_t>> merged;
+      for (auto& f : freel) {
+        if (!merged.empty() && merged.back().first + merged.back().second == f.first) merged.back().second += f.second;
+        else merged.push_back(f);
+      }
+      freel.swap(merged);
+      for (int s : by_level[l]) {
+        Front& F = P.fronts[s];
+        if (F.ri == 0) continue;
+        bool placed = false;
+        for (auto& f : freel)
+          if (f.second >= F.ri) { F.c_off = f.first; f.first += F.ri; f.second -= F.ri; placed = true; break; }
+        if (!placed) { F.c_off = coff; coff += F.ri; }
+        const int pl = P.fronts[F.parent].level;
+        release[std::min(pl + 1, nl)].push_back(s);
+      }
+    }
   }
   P.scratch_size = foff; P.factor_size = fac; P.contrib_size = coff;
   // --- relative maps (update rows -> position in the parent's index list / separator id)
@@ -342,7 +373,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
       for (int pass = 0; pass < 2; pass++)
         for (int s : (pass == 0 ? P.levels[l] : P.big_levels[l])) {
           Front& F = P.fronts[s];
-          F.lf_off = lf; lf += F.w + F.ri;
+          F.lf_off = lf; lf += F.w;   // only the pivot part of the assembled vector needs its own space
           if (nf < 65536 && F.w + F.ri < 65536) {
             for (int r = 0; r < F.w + F.ri; r++) P.fw_items.push_back((s << 16) | r);
             for (int r = 0; r < F.w; r++) P.bw_items.push_back((s << 16) | r);

@@ -217,7 +217,7 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
         const int r = P.fw_items[it] & 0xffff;
         double v = r < F.w ? X[F.c0 + r] : 0.0;
         for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) v += C[P.asm_src[t]];
-        Fv[F.lf_off + r] = v;
+        if (r < F.w) Fv[F.lf_off + r] = v; else C[F.c_off + r - F.w] = v;   // update rows are assembled in place
       }
       for (int it = P.fw_ptr[lev]; it < P.fw_ptr[lev + 1]; it++) {
         const FrontD& F = P.fronts[P.fw_items[it] >> 16];
@@ -226,7 +226,7 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
         const int kmax = r < w ? r : w;
         double a = 0;
         for (int k = 0; k < kmax; k++) a += Lp[r + (int64_t)ld * k] * Fv[F.lf_off + k];
-        if (r < w) X[F.c0 + r] = Fv[F.lf_off + r] + a; else C[F.c_off + r - w] = Fv[F.lf_off + r] - a;
+        if (r < w) X[F.c0 + r] = Fv[F.lf_off + r] + a; else C[F.c_off + r - w] -= a;
       }
     }
     for (int lev = P.nlev - 1; lev >= 0; lev--) {

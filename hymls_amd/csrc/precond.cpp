@@ -178,7 +178,7 @@ int32_t BatchedLU::check_flag() const {
 
 // ------------------------------------------------------------------ DirectSolver
 DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids, int64_t ngid,
-                           const Params& cp) {
+                           const Params& cp, const ivec* clu_ptr, const ivec* clu, const ivec* clu_coord) {
   // CoarseSolver::Compute (reference src/HYMLS_CoarseSolver.cpp:131-152)
   Csr A = drop_by_value(A0, SMALL_ENTRY, 2);
   n_ = A.n;
@@ -205,6 +205,7 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   lp.coord.resize(3 * (size_t)n_);
   for (int i = 0; i < n_; i++) gid_coord(cp, gids[i], &lp.coord[3 * (size_t)i]);
   (void)ngid;
+  if (clu_ptr && !clu_ptr->empty() && !std::getenv("HYMLS_MI_NO_CLUSTER_ND")) { lp.clu_ptr = *clu_ptr; lp.clu = *clu; lp.clu_coord = *clu_coord; }
   lu_.reset(new BatchedLU());
   lu_->plan = analyse_class(lp, LEAF_SIZE_COARSE, MAX_WIDTH_COARSE, 65536);
   if (std::getenv("HYMLS_MI_VERBOSE")) print_plan_stats(lu_->plan, "coarse solver", 1);
@@ -360,6 +361,15 @@ void LevelSolver::build_classes() {
     for (int i = cnt[a]; i < cnt[a + 1]; i++) for (int j = cnt[b]; j < cnt[b + 1]; j++) c += sdl[i] == sdl[j];
     return c;
   };
+  sep_sd_ptr_ = cnt; sep_sd_ = sdl;
+  sd_center_.assign(3 * (size_t)nsd, 0);
+  for (int s = 0; s < nsd; s++) {
+    int64_t acc[3] = {0, 0, 0}, m = 0;
+    int32_t cc[3];
+    for (auto& g : hm_.sd[s].groups) { gid_coord(p_, g.nodes[0], cc); for (int a = 0; a < 3; a++) acc[a] += cc[a]; m++; }
+    for (int32_t x : hm_.sd[s].interior) { gid_coord(p_, x, cc); for (int a = 0; a < 3; a++) acc[a] += cc[a]; m++; if (m > 64) break; }
+    for (int a = 0; a < 3; a++) sd_center_[3 * (size_t)s + a] = m ? (int32_t)(acc[a] / m) : 0;
+  }
   sd_xoff_.assign(nsd, 0); sd_cls_.assign(nsd, -1); sd_bidx_.assign(nsd, -1);
   ivec loc(n, -1);
   std::unordered_map<uint64_t, std::vector<int>> table;
@@ -687,7 +697,7 @@ void LevelSolver::compute() {
     Csr S = drop_by_value(red_, SMALL_ENTRY, 1);
     next_.reset();
     next_level_ = nullptr;
-    next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_));
+    next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &sep_sd_ptr_, &sep_sd_, &sd_center_));
     return;
   }
   dev::zero(d_flag_, sizeof(int32_t));
@@ -728,7 +738,12 @@ void LevelSolver::compute() {
     next_level_->compute();
   } else {
     next_level_ = nullptr;
-    next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_));
+    ivec cp(1, 0), cl;
+    for (int g = 0; g < ng; g++) {
+      for (int t = sep_sd_ptr_[vs_[g]]; t < sep_sd_ptr_[vs_[g] + 1]; t++) cl.push_back(sep_sd_[t]);
+      cp.push_back((int32_t)cl.size());
+    }
+    next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &cp, &cl, &sd_center_));
   }
 }
 

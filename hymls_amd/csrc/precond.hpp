@@ -55,7 +55,9 @@ class Operator {  // something with ApplyInverse on device vectors in its own ro
 // CoarseSolver: exact sparse LU of one matrix (after dropping / Dirichlet fixes)
 class DirectSolver : public Operator {
  public:
-  DirectSolver(const Csr& A, const ivec& gids, const ivec& fix_gids, int64_t ngid, const Params& coord_params);
+  // clu_ptr/clu/clu_coord: optional clusters of the rows (see LocalPattern::clu)
+  DirectSolver(const Csr& A, const ivec& gids, const ivec& fix_gids, int64_t ngid, const Params& coord_params,
+               const ivec* clu_ptr = nullptr, const ivec* clu = nullptr, const ivec* clu_coord = nullptr);
   ~DirectSolver() override;
   void apply_inverse(const double* b, double* x) override;
   int64_t size() const override { return n_; }
@@ -113,6 +115,8 @@ class LevelSolver : public Operator {
   ivec intidx_;              // level row -> internal interior index (-1)
   ivec in_perm_;             // internal index -> level row
   ivec sd_xoff_, sd_cls_, sd_bidx_;
+  ivec sep_sd_ptr_, sep_sd_;   // per separator index: the subdomains whose groups contain it
+  ivec sd_center_;             // 3 ints per subdomain (mean coordinate of its separator nodes)
   std::vector<std::unique_ptr<Cls>> cls_;
   // fused interior solve tables
   dev::FusedSub* d_fsubs_ = nullptr;

@@ -134,6 +134,73 @@ void nd_recurse(NdCtx& c, ivec& nodes) {
   if (!sep.empty()) emit_leaf(sep);
 }
 
+// Nested dissection on cluster centres (see LocalPattern::clu).  nlo/nhi per node and direction are
+// recomputed per call from the clusters (<= 8 per node).
+struct CluCtx {
+  const ivec* cptr; const ivec* cids; const ivec* ccoord;
+  const std::vector<ivec>* vclu;   // per V-node: its clusters incl. those of its P neighbours
+  inline int cproj(int cl, int d) const {
+    const ivec& co = *ccoord;
+    return co[3 * cl] * DIRS[d][0] + co[3 * cl + 1] * DIRS[d][1] + co[3 * cl + 2] * DIRS[d][2];
+  }
+};
+
+void nd_cluster_recurse(NdCtx& c, const CluCtx& k, ivec& nodes) {
+  const int n = (int)nodes.size();
+  if (n == 0) return;
+  auto emit_leaf = [&](ivec& v) {
+    const ivec& co = *c.coord;
+    std::sort(v.begin(), v.end(), [&](int a, int b) {
+      if (co[3 * a + 2] != co[3 * b + 2]) return co[3 * a + 2] < co[3 * b + 2];
+      if (co[3 * a + 1] != co[3 * b + 1]) return co[3 * a + 1] < co[3 * b + 1];
+      if (co[3 * a] != co[3 * b]) return co[3 * a] < co[3 * b];
+      return a < b;
+    });
+    const int b = (int)c.order.size();
+    c.order.insert(c.order.end(), v.begin(), v.end());
+    c.snodes.emplace_back(b, (int)c.order.size());
+  };
+  if (n <= c.leaf) { emit_leaf(nodes); return; }
+  double best_score = 1e300;
+  int best_d = -1, best_t = 0;
+  ivec lo(n), hi(n), slo, shi, cand;
+  for (int d = 0; d < NDIR; d++) {
+    cand.clear();
+    for (int i = 0; i < n; i++) {
+      int a = INT32_MAX, b = INT32_MIN;
+      for (int cl : (*k.vclu)[nodes[i]]) { const int p = k.cproj(cl, d); a = std::min(a, p); b = std::max(b, p); cand.push_back(p); }
+      lo[i] = a; hi[i] = b;
+    }
+    std::sort(cand.begin(), cand.end());
+    cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+    slo = lo; shi = hi;
+    std::sort(slo.begin(), slo.end()); std::sort(shi.begin(), shi.end());
+    for (int t : cand) {
+      // clusters with projection < t are "left": L = nodes with hi < t, R = nodes with lo >= t
+      const int nL = (int)(std::lower_bound(shi.begin(), shi.end(), t) - shi.begin());
+      const int nR = n - (int)(std::lower_bound(slo.begin(), slo.end(), t) - slo.begin());
+      if (nL == 0 || nR == 0) continue;
+      const int sep = n - nL - nR;
+      const double imb = std::abs(nL - nR) / (double)n;
+      if (imb > 0.6) continue;
+      const double score = (sep + 1.0) * (1.0 + 2.0 * imb);
+      if (score < best_score) { best_score = score; best_d = d; best_t = t; }
+    }
+  }
+  if (best_d < 0) { emit_leaf(nodes); return; }
+  ivec L, R, S;
+  for (int i = 0; i < n; i++) {
+    int a = INT32_MAX, b = INT32_MIN;
+    for (int cl : (*k.vclu)[nodes[i]]) { const int p = k.cproj(cl, best_d); a = std::min(a, p); b = std::max(b, p); }
+    if (b < best_t) L.push_back(nodes[i]);
+    else if (a >= best_t) R.push_back(nodes[i]);
+    else S.push_back(nodes[i]);
+  }
+  nd_cluster_recurse(c, k, L);
+  nd_cluster_recurse(c, k, R);
+  if (!S.empty()) emit_leaf(S);
+}
+
 }  // namespace
 
 void print_plan_stats(const ClassPlan& P, const char* label, int nmembers) {
@@ -181,7 +248,23 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   }
   ivec vnodes;
   for (int i = 0; i < nI; i++) if (!lp.zero_diag[i]) vnodes.push_back(i);
-  nd_recurse(c, vnodes);
+  if (!lp.clu_ptr.empty()) {
+    // cluster-based dissection: a V-node carries its own clusters and those of its P neighbours
+    // (eliminating the pressure right after it connects all velocities of that pressure)
+    std::vector<ivec> vclu(nI);
+    for (int v : vnodes) {
+      ivec& cl = vclu[v];
+      cl.assign(lp.clu.begin() + lp.clu_ptr[v], lp.clu.begin() + lp.clu_ptr[v + 1]);
+      for (int p : pv[v]) cl.insert(cl.end(), lp.clu.begin() + lp.clu_ptr[p], lp.clu.begin() + lp.clu_ptr[p + 1]);
+      std::sort(cl.begin(), cl.end());
+      cl.erase(std::unique(cl.begin(), cl.end()), cl.end());
+      HYMLS_CHECK(!cl.empty(), -3, "node without cluster");
+    }
+    CluCtx k{&lp.clu_ptr, &lp.clu, &lp.clu_coord, &vclu};
+    nd_cluster_recurse(c, k, vnodes);
+  } else {
+    nd_recurse(c, vnodes);
+  }
   // --- attach every P-node behind a V-node that grounds it (union-find over pressures;
   //     the id nI stands for "boundary / separator / no second pressure")
   ivec uf(nI + 1);

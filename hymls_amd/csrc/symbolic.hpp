@@ -25,6 +25,11 @@ struct LocalPattern {
   std::vector<char> zero_diag;  // size nI: row has no / a zero diagonal ("P-node")
   ivec coord;                // 3 * nI integer coordinates (for nested dissection)
   dvec weight;               // per entry: 1, or 1/multiplicity for separator-separator entries
+  // optional clusters (V-sum graphs: the finer-level subdomains every node belongs to).  Two nodes
+  // are adjacent only if they share a cluster, so a vertex separator = nodes whose clusters lie
+  // on both sides of a cut through the cluster centres (thin, unlike a cut through node positions).
+  ivec clu_ptr, clu;         // CSR node -> cluster ids (interior nodes only; empty = unused)
+  ivec clu_coord;            // 3 ints per cluster
 };
 
 struct Front {

@@ -147,13 +147,22 @@ def main():
         bytes_launch = bytes_all[1] / 2.0 + 16.0 * n1
         t_launch = t_phase[1] / 2.0
         achieved = bytes_launch / t_launch / 1e9 if t_launch > 0 else None
-        traffic = None
+        # HBM traffic of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
+        # gfx950 1/2-fetch correction calibrated in the same pass): committed measurement, used only when it was
+        # taken on this very workload; rocprofv3 --pmc crashes at 128^3, so the 112^3 measurement is attached as
+        # `traffic_measured_on` and `traffic` stays null for the default grid.
+        traffic, traffic_other = None, None
         prof = os.path.join(ROOT, "profiles", "r01_pmc_interior_fused.json")
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
                 if pj.get("n") == n and pj.get("sx") == sx and pj.get("levels") == levels:
                     traffic = pj.get("hbm_bytes_per_launch")
+                else:
+                    traffic_other = {"workload": "Stokes3D %d^3, sx=%d, Number of Levels=%d" % (pj["n"], pj["sx"], pj["levels"]),
+                                     "hbm_bytes_per_launch": pj["hbm_bytes_per_launch"],
+                                     "algorithmic_bytes_per_launch": pj["algorithmic_bytes_per_launch"],
+                                     "traffic_over_algorithmic": pj["traffic_over_algorithmic"]}
             except Exception:
                 traffic = None
         out = {
@@ -173,7 +182,7 @@ def main():
                          "schur": 1e3 * t_phase[3], "coarse": 1e3 * t_phase[4]},
             "roofline": {"kernel": "k_interior_fused", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
-                         "bytes_per_launch": bytes_launch, "launch_ms": 1e3 * t_launch},
+                         "bytes_per_launch": bytes_launch, "launch_ms": 1e3 * t_launch, "traffic_measured_on": traffic_other},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, sx, levels)

@@ -7,6 +7,8 @@ reference src/HYMLS_Preconditioner.hpp:56-254) on top of the C ABI declared in
 code + hand-written HIP kernels for gfx950).  There is no CPU fallback: if the
 HIP library is missing, importing :class:`Preconditioner` users get a loud error.
 """
-from .api import Preconditioner, HymlsError, load_library, generate_matrix, generate_testvector, LIB_PATH
+from .api import (Preconditioner, HymlsError, load_library, generate_matrix, generate_testvector, generate_rows,
+                  generate_testvector_rows, LIB_PATH)
 
-__all__ = ["Preconditioner", "HymlsError", "load_library", "generate_matrix", "generate_testvector", "LIB_PATH"]
+__all__ = ["Preconditioner", "HymlsError", "load_library", "generate_matrix", "generate_testvector", "generate_rows",
+           "generate_testvector_rows", "LIB_PATH"]

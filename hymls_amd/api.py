@@ -28,8 +28,17 @@ class _Params(C.Structure):
 
 
 _I32P = C.POINTER(C.c_int32)
+_I64P = C.POINTER(C.c_int64)
 _F64P = C.POINTER(C.c_double)
 _libs = {}
+
+# transport callbacks of a sharded run (include/hymls_mi.h: hymls_mi_comm)
+A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, _I64P, C.c_void_p, _I64P, C.c_int32, C.c_int32)
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int64)
+
+
+class _Comm(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("size", C.c_int32), ("alltoallv", A2A_FN), ("alloc", ALLOC_FN)]
 
 
 def load_library(path=None):
@@ -55,6 +64,12 @@ def load_library(path=None):
         "hymls_mi_default_params": (None, [C.POINTER(_Params)]),
         "hymls_mi_create": (C.c_int, [C.POINTER(H), C.POINTER(_Params), C.c_int]),
         "hymls_mi_set_matrix_csr": (C.c_int, [H, C.c_int64, _I32P, _I32P, _F64P]),
+        "hymls_mi_set_comm": (C.c_int, [H, C.POINTER(_Comm), C.c_int, C.c_int, C.c_int]),
+        "hymls_mi_required_rows": (C.c_int, [H, _I64P, _I32P]),
+        "hymls_mi_set_matrix_rows": (C.c_int, [H, C.c_int64, _I32P, _I32P, _I32P, _F64P]),
+        "hymls_mi_owned_rows": (C.c_int, [H, _I64P, _I32P]),
+        "hymls_mi_generate_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int64, _I32P,
+                                             _I64P, _I32P, _I32P, _F64P]),
         "hymls_mi_set_testvector": (C.c_int, [H, _F64P]),
         "hymls_mi_initialize": (C.c_int, [H]),
         "hymls_mi_compute": (C.c_int, [H]),
@@ -121,6 +136,36 @@ def generate_matrix(equations, nx, ny, nz, a=None, b=1.0, lib=None):
     return rowptr, col, val
 
 
+def generate_rows(equations, nx, ny, nz, gids, a=None, b=1.0, lib=None):
+    """CSR arrays (rowptr, global colind, val) of the rows `gids` of the same matrices (what one rank
+    of a sharded run generates for itself)."""
+    lib = lib or load_library()
+    eq = {"Laplace": 0, "Stokes-C": 1}[equations]
+    if a is None:
+        a = float(nx * nx)
+    gids = np.ascontiguousarray(gids, dtype=np.int32)
+    nnz = C.c_int64()
+    ierr = lib.hymls_mi_generate_rows(eq, nx, ny, nz, a, b, gids.size, _i32(gids), C.byref(nnz), None, None, None)
+    if ierr:
+        raise HymlsError(ierr, "generate_rows")
+    rowptr = np.empty(gids.size + 1, np.int32)
+    col = np.empty(max(nnz.value, 1), np.int32)
+    val = np.empty(max(nnz.value, 1), np.float64)
+    lib.hymls_mi_generate_rows(eq, nx, ny, nz, a, b, gids.size, _i32(gids), C.byref(nnz), _i32(rowptr), _i32(col), _f64(val))
+    return rowptr, col[:nnz.value], val[:nnz.value]
+
+
+def generate_testvector_rows(gids, rowptr, col, val):
+    """create_testvector for a list of rows with global column ids (0 for rows that only have a
+    diagonal entry, 1 otherwise; reference src/HYMLS_MainUtils.cpp:208-258)."""
+    gids = np.asarray(gids)
+    rows = np.repeat(np.arange(gids.size), np.diff(rowptr))
+    off = (val != 0.0) & (col != gids[rows])
+    tv = np.zeros(gids.size)
+    tv[np.unique(rows[off])] = 1.0
+    return tv
+
+
 def generate_testvector(rowptr, col, val, lib=None):
     lib = lib or load_library()
     tv = np.empty(rowptr.size - 1, np.float64)
@@ -142,7 +187,10 @@ class Preconditioner:
                "Preconditioner": {"Separator Length": 8, "Number of Levels": 1, "Partitioner": "Cartesian"}}
     """
 
-    def __init__(self, K, params, testVector=None, device=0, lib=None):
+    def __init__(self, K, params, testVector=None, device=0, lib=None, comm=None, rank_grid=None):
+        """comm / rank_grid: sharded run (one process per GPU): `comm` is a hymls_amd.dist.TorchComm,
+        rank_grid = (px, py, pz) boxes of the grid; K may then be None (call RequiredRows(), then
+        SetMatrixRows(gids, (rowptr, global colind, val)) with this rank's rows)."""
         self._lib = load_library(lib) if (lib is None or isinstance(lib, str)) else lib
         self._h = C.c_void_p()
         self._params = params
@@ -152,10 +200,43 @@ class Preconditioner:
         ierr = self._lib.hymls_mi_create(C.byref(self._h), C.byref(p), device)
         self._check(ierr)
         self._n = None
-        self.SetMatrix(K)
+        self._comm = comm
+        if comm is not None:
+            comm.attach(self)
+            px, py, pz = rank_grid
+            self._check(self._lib.hymls_mi_set_comm(self._h, C.byref(comm.c_struct), px, py, pz))
+        if K is not None:
+            self.SetMatrix(K)
         if testVector is not None:
-            tv = np.ascontiguousarray(testVector, dtype=np.float64)
-            self._check(self._lib.hymls_mi_set_testvector(self._h, _f64(tv)))
+            self.SetTestVector(testVector)
+
+    # --- sharded runs
+    def RequiredRows(self):
+        n = C.c_int64()
+        self._check(self._lib.hymls_mi_required_rows(self._h, C.byref(n), None))
+        g = np.empty(n.value, np.int32)
+        self._check(self._lib.hymls_mi_required_rows(self._h, C.byref(n), _i32(g)))
+        return g
+
+    def SetMatrixRows(self, gids, K):
+        gids = np.ascontiguousarray(gids, dtype=np.int32)
+        rowptr = np.ascontiguousarray(K[0], dtype=np.int32)
+        col = np.ascontiguousarray(K[1], dtype=np.int32)
+        val = np.ascontiguousarray(K[2], dtype=np.float64)
+        self._check(self._lib.hymls_mi_set_matrix_rows(self._h, gids.size, _i32(gids), _i32(rowptr), _i32(col), _f64(val)))
+        return 0
+
+    def SetTestVector(self, tv):
+        tv = np.ascontiguousarray(tv, dtype=np.float64)
+        self._check(self._lib.hymls_mi_set_testvector(self._h, _f64(tv)))
+
+    def OwnedRows(self):
+        n = C.c_int64()
+        self._check(self._lib.hymls_mi_owned_rows(self._h, C.byref(n), None))
+        g = np.empty(n.value, np.int32)
+        self._check(self._lib.hymls_mi_owned_rows(self._h, C.byref(n), _i32(g)))
+        self._n = int(n.value)
+        return g
 
     @staticmethod
     def _fill(p, params):
@@ -222,10 +303,14 @@ class Preconditioner:
 
     def Initialize(self):
         self._check(self._lib.hymls_mi_initialize(self._h))
+        if self._comm is not None:
+            self.OwnedRows()
         return 0
 
     def Compute(self):
         self._check(self._lib.hymls_mi_compute(self._h))
+        if self._comm is not None:
+            self.OwnedRows()
         return 0
 
     def IsInitialized(self):

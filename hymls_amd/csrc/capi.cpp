@@ -7,6 +7,8 @@
 namespace hymls {
 int64_t generate_laplace3d(int nx, int ny, int nz, int32_t* rowptr, int32_t* col, double* val);
 int64_t generate_stokes3d(int nx, int ny, int nz, double a, double b, int32_t* rowptr, int32_t* col, double* val);
+int64_t generate_rows(int equations, int nx, int ny, int nz, double a, double b, int64_t nrows, const int32_t* gids,
+                      int32_t* rowptr, int32_t* col, double* val);
 }
 
 using namespace hymls;
@@ -16,10 +18,15 @@ struct hymls_mi {
   int device = 0;
   Csr K;
   bool have_matrix = false;
+  Comm comm;                 // one rank unless hymls_mi_set_comm was called
+  ivec gids;                 // local nodes of K (sharded: rows given + ghost columns)
+  int32_t nrows = 0;         // local nodes with a row
+  ivec rows_rowptr, rows_colgid;   // sharded: the rows as they were given (pattern check of SetMatrix)
+  int64_t ngid() const { return (int64_t)p.nx * p.ny * p.nz * p.dof; }
   dvec tv;
   std::unique_ptr<LevelSolver> top;
   bool initialized = false, computed = false;
-  int n_init = 0, n_comp = 0, n_apply = 0;
+  int n_init = 0, n_comp = 0, n_apply = 0, n_init_top = 0;
   double t_init = 0, t_comp = 0, t_apply = 0;
   std::string err;
   double *d_b = nullptr, *d_x = nullptr;
@@ -96,7 +103,8 @@ int hymls_mi_create(hymls_mi_t** out, const hymls_mi_params* q, int device) {
 int hymls_mi_set_matrix_csr(hymls_mi_t* h, int64_t n, const int32_t* rowptr, const int32_t* colind, const double* val) {
   if (!h) return -2;
   API_BEGIN
-  const int64_t N = (int64_t)h->p.nx * h->p.ny * h->p.nz * h->p.dof;
+  const int64_t N = h->ngid();
+  HYMLS_CHECK(!h->comm.distributed(), -2, "sharded handle: pass this rank's rows with hymls_mi_set_matrix_rows");
   HYMLS_CHECK(n == N, -2, "matrix size does not match nx*ny*nz*dof");
   const int64_t nnz = rowptr[n];
   const bool same = h->have_matrix && h->K.n == n && (int64_t)h->K.col.size() == nnz &&
@@ -106,6 +114,9 @@ int hymls_mi_set_matrix_csr(hymls_mi_t* h, int64_t n, const int32_t* rowptr, con
   h->K.rowptr.assign(rowptr, rowptr + n + 1);
   h->K.col.assign(colind, colind + nnz);
   h->K.val.assign(val, val + nnz);
+  h->gids.resize(n);
+  std::iota(h->gids.begin(), h->gids.end(), 0);
+  h->nrows = (int32_t)n;
   h->have_matrix = true;
   h->computed = false;
   if (same && h->top) h->top->set_values(h->K.val);   // SetMatrix: pattern reused
@@ -113,12 +124,73 @@ int hymls_mi_set_matrix_csr(hymls_mi_t* h, int64_t n, const int32_t* rowptr, con
   API_END(h)
 }
 
+int hymls_mi_set_comm(hymls_mi_t* h, const hymls_mi_comm* c, int px, int py, int pz) {
+  if (!h || !c) return -2;
+  API_BEGIN
+  HYMLS_CHECK(c->size >= 1 && c->rank >= 0 && c->rank < c->size && px * py * pz == c->size, -2,
+              "rank grid px*py*pz must equal the number of ranks");
+  HYMLS_CHECK(c->size == 1 || (c->alltoallv && c->alloc), -2, "a sharded run needs both transport callbacks");
+  h->comm.rank = c->rank; h->comm.size = c->size; h->comm.ctx = c->ctx;
+  h->comm.px = px; h->comm.py = py; h->comm.pz = pz;
+  h->comm.alltoallv = c->alltoallv; h->comm.alloc = c->alloc;
+  h->top.reset(); h->initialized = false; h->computed = false; h->have_matrix = false;
+  API_END(h)
+}
+
+int hymls_mi_required_rows(hymls_mi_t* h, int64_t* n, int32_t* gids) {
+  if (!h || !n) return -2;
+  API_BEGIN
+  if (!h->top) { h->top.reset(new LevelSolver(h->p, 0, h->ngid(), &h->comm)); h->initialized = false; h->n_init_top = 0; }
+  h->top->partition(nullptr);
+  ivec r = h->top->required_gids();
+  *n = (int64_t)r.size();
+  if (gids) std::copy(r.begin(), r.end(), gids);
+  API_END(h)
+}
+
+int hymls_mi_set_matrix_rows(hymls_mi_t* h, int64_t nrows, const int32_t* gids, const int32_t* rowptr,
+                             const int32_t* colgid, const double* val) {
+  if (!h || !gids || !rowptr) return -2;
+  API_BEGIN
+  const int64_t nnz = rowptr[nrows];
+  const bool same = h->have_matrix && h->nrows == nrows && (int64_t)h->rows_colgid.size() == nnz &&
+                    std::memcmp(h->gids.data(), gids, nrows * 4) == 0 &&
+                    std::memcmp(h->rows_rowptr.data(), rowptr, (nrows + 1) * 4) == 0 &&
+                    std::memcmp(h->rows_colgid.data(), colgid, nnz * 4) == 0;
+  h->computed = false;
+  if (same && h->top && h->initialized) {
+    h->K.val.assign(val, val + nnz);
+    h->top->set_values(h->K.val);
+  } else {
+    make_local_csr(nrows, gids, rowptr, colgid, val, h->ngid(), h->K, h->gids);
+    h->nrows = (int32_t)nrows;
+    h->rows_rowptr.assign(rowptr, rowptr + nrows + 1);
+    h->rows_colgid.assign(colgid, colgid + nnz);
+    h->have_matrix = true;
+    h->initialized = false;
+    h->tv.clear();
+  }
+  API_END(h)
+}
+
+int hymls_mi_owned_rows(const hymls_mi_t* hc, int64_t* n, int32_t* gids) {
+  hymls_mi_t* h = const_cast<hymls_mi_t*>(hc);
+  if (!h || !n) return -2;
+  API_BEGIN
+  HYMLS_CHECK(h->initialized && h->top, -1, "not initialized");
+  const ivec& o = h->top->owned_gids();
+  *n = (int64_t)o.size();
+  if (gids) std::copy(o.begin(), o.end(), gids);
+  API_END(h)
+}
+
 int hymls_mi_set_testvector(hymls_mi_t* h, const double* v) {
   if (!h) return -2;
   API_BEGIN
   HYMLS_CHECK(h->have_matrix, -1, "set the matrix first");
-  h->tv.assign(v, v + h->K.n);
-  h->top.reset(); h->initialized = false; h->computed = false;
+  h->tv.assign(v, v + h->nrows);
+  if (!h->comm.distributed()) h->top.reset();
+  h->initialized = false; h->computed = false;
   API_END(h)
 }
 
@@ -127,10 +199,11 @@ int hymls_mi_initialize(hymls_mi_t* h) {
   API_BEGIN
   HYMLS_CHECK(h->have_matrix, -1, "no matrix set");
   const double t0 = now();
-  if (h->tv.empty()) h->tv.assign(h->K.n, 1.0);
-  ivec gids(h->K.n);
-  std::iota(gids.begin(), gids.end(), 0);
-  h->top.reset(new LevelSolver(h->p, 0, h->K, gids, h->tv, (int64_t)h->K.n));
+  if (h->tv.empty()) h->tv.assign(h->nrows, 1.0);
+  // sharded: keep the partition hymls_mi_required_rows already made, unless it was used up by an earlier Initialize
+  if (!h->top || h->n_init_top) h->top.reset(new LevelSolver(h->p, 0, h->ngid(), &h->comm));
+  h->n_init_top = 1;
+  h->top->set_rows(h->K, h->gids, h->tv, h->nrows);
   h->top->initialize();
   h->top->profiling = h->profiling;
   h->initialized = true; h->computed = false;
@@ -160,7 +233,7 @@ int hymls_mi_apply_inverse(hymls_mi_t* h, const double* B, int64_t ldb, double* 
   API_BEGIN
   HYMLS_CHECK(h->computed, -1, "The preconditioner has not yet been computed.");
   const double t0 = now();
-  const int64_t n = h->K.n;
+  const int64_t n = h->top->num_owned();
   if (!on_device && h->buf_n < n) {
     dev::free(h->d_b); dev::free(h->d_x);
     h->d_b = (double*)dev::alloc(n * sizeof(double));
@@ -187,7 +260,7 @@ int hymls_mi_matvec(hymls_mi_t* h, const double* X, double* Y, int on_device) {
   if (!h) return -2;
   API_BEGIN
   HYMLS_CHECK(h->computed, -1, "matvec needs a computed preconditioner (device copy of K)");
-  const int64_t n = h->K.n;
+  const int64_t n = h->top->num_owned();
   if (on_device) { h->top->matvec(X, Y); }
   else {
     if (h->buf_n < n) {
@@ -321,6 +394,14 @@ int hymls_mi_generate_matrix(int equations, int nx, int ny, int nz, double a, do
   } else {
     return -99;
   }
+  return 0;
+}
+
+int hymls_mi_generate_rows(int equations, int nx, int ny, int nz, double a, double b, int64_t nrows, const int32_t* gids,
+                           int64_t* nnz, int32_t* rowptr, int32_t* colgid, double* val) {
+  if (!nnz || !gids || (equations != 0 && equations != 1)) return -2;
+  try { *nnz = generate_rows(equations, nx, ny, nz, a, b, nrows, gids, rowptr, colgid, val); }
+  catch (...) { return -2; }
   return 0;
 }
 

@@ -119,15 +119,28 @@ static void link_groups(const std::vector<Group>& groups, const ivec& idxs, std:
 
 void skew_get_groups(const Params& p, int sd, ivec& interior, std::vector<Group>& groups);
 int skew_num_subdomains(const Params& p);
+void skew_sd_position(const Params& p, int sd, int& x, int& y, int& z);
 
-HierMap build_hiermap(const Params& p, const std::vector<char>* present) {
+int num_subdomains(const Params& p) { return p.partitioner == 0 ? cartesian_num_subdomains(p) : skew_num_subdomains(p); }
+
+void sd_position(const Params& p, int sd, int& x, int& y, int& z) {
+  if (p.partitioner == 0) {
+    const int npx = (p.nx - 1) / p.sx + 1, npy = (p.ny - 1) / p.sy + 1, npz = (p.nz - 1) / p.sz + 1;
+    x = (sd % npx) * p.sx; y = ((sd / npx) % npy) * p.sy; z = ((sd / npx / npy) % npz) * p.sz;
+  } else {
+    skew_sd_position(p, sd, x, y, z);
+  }
+}
+
+HierMap build_hiermap(const Params& p, const std::vector<char>* present, const std::vector<char>* cand) {
   HierMap h;
   h.ngid = (int64_t)p.nx * p.ny * p.nz * p.dof;
   HYMLS_CHECK(h.ngid < (int64_t)1 << 31, -2, "more than 2^31 unknowns need 64-bit GIDs");
-  const int nsd = p.partitioner == 0 ? cartesian_num_subdomains(p) : skew_num_subdomains(p);
+  const int nsd = num_subdomains(p);
   h.sd.resize(nsd);
   std::vector<char> seen(h.ngid, 0);  // first gid of every group already owned
   for (int s = 0; s < nsd; s++) {
+    if (cand && !(*cand)[s]) continue;
     Subdomain& S = h.sd[s];
     std::vector<Group> raw;
     if (p.partitioner == 0) cartesian_get_groups(p, s, S.interior, raw);

@@ -36,7 +36,14 @@ void cartesian_get_groups(const Params& p, int sd, ivec& interior, std::vector<G
 int cartesian_num_subdomains(const Params& p);
 
 // all subdomains + FillComplete semantics; `present` (size ngid) marks gids that
-// exist on this level (nullptr: all).
-HierMap build_hiermap(const Params& p, const std::vector<char>* present);
+// exist on this level (nullptr: all).  `cand` (size = number of subdomains, nullptr: all) restricts
+// the work to a subset of the subdomains (sharded runs: the rank's own subdomains plus a halo);
+// the others stay empty, and "first listed by" is then relative to the subset.
+HierMap build_hiermap(const Params& p, const std::vector<char>* present, const std::vector<char>* cand = nullptr);
+int num_subdomains(const Params& p);
+// reference corner of a subdomain in cell coordinates (may lie outside the grid for the clipped
+// diamonds of the Skew Cartesian partitioner); every node of the subdomain and of its separators is
+// within [pos - sx - 1, pos + sx + 1] in each direction
+void sd_position(const Params& p, int sd, int& x, int& y, int& z);
 
 }  // namespace hymls

@@ -269,73 +269,255 @@ struct LevelSolver::Cls {
   ~Cls() { dev::free(d_pick); dev::free(d_lgptr); dev::free(d_tvloc); }
 };
 
-LevelSolver::LevelSolver(const Params& p, int level, Csr K, ivec gids, dvec testvec, int64_t ngid)
-    : p_(p), level_(level), K_(std::move(K)), gids_(std::move(gids)), tv_(std::move(testvec)), ngid_(ngid) {}
+void make_local_csr(int64_t nrows, const int32_t* row_gids, const int32_t* rowptr, const int32_t* col_gids,
+                    const double* val, int64_t ngid, Csr& K, ivec& gids) {
+  ivec g2l(ngid, -1);
+  for (int64_t i = 0; i < nrows; i++) {
+    HYMLS_CHECK(row_gids[i] >= 0 && row_gids[i] < ngid && g2l[row_gids[i]] < 0, -2, "row gid out of range or given twice");
+    g2l[row_gids[i]] = (int32_t)i;
+  }
+  const int64_t nnz = rowptr[nrows];
+  ivec ghosts;
+  for (int64_t e = 0; e < nnz; e++) {
+    const int32_t c = col_gids[e];
+    HYMLS_CHECK(c >= 0 && c < ngid, -2, "column gid out of range");
+    if (g2l[c] == -1) { g2l[c] = -2; ghosts.push_back(c); }
+  }
+  std::sort(ghosts.begin(), ghosts.end());
+  gids.assign(row_gids, row_gids + nrows);
+  for (int32_t g : ghosts) { g2l[g] = (int32_t)gids.size(); gids.push_back(g); }
+  K.n = (int32_t)gids.size();
+  K.rowptr.assign(K.n + 1, (int32_t)nnz);
+  std::copy(rowptr, rowptr + nrows + 1, K.rowptr.begin());
+  K.col.resize(nnz);
+  for (int64_t e = 0; e < nnz; e++) K.col[e] = g2l[col_gids[e]];
+  K.val.assign(val, val + nnz);
+}
+
+LevelSolver::LevelSolver(const Params& p, int level, int64_t ngid, const Comm* comm)
+    : p_(p), level_(level), ngid_(ngid), comm_(comm) {}
 
 LevelSolver::~LevelSolver() {
   void* ptrs[] = {d_kval_, d_krow_, d_kcol_, d_inperm_, d_z_, d_t1_, d_t2_, d_y2_, d_a12_row_, d_a12_col_,
                   d_a12_src_, d_a21_row_, d_a21_col_, d_a21_src_, d_a12_val_, d_a21_val_, d_gptr_, d_otw_,
-                  d_vs_, d_red_pull_ptr_, d_red_pull_idx_, d_red_val_, d_ext_, d_vrhs_, d_vsol_, d_yb_, d_flag_};
+                  d_vs_, d_red_pull_ptr_, d_red_pull_idx_, d_red_val_, d_ext_, d_vrhs_, d_vsol_, d_yb_, d_flag_,
+                  d_nrhs_, d_nsol_};
   for (void* q : ptrs) dev::free(q);
   dev::free(d_fsubs_); dev::free(d_fplans_);
   for (auto& b : blocks_) { dev::free(b.d_binv); dev::free(b.d_ids); dev::free(b.d_pull_ptr); dev::free(b.d_pull_base); }
 }
 
+void LevelSolver::set_rows(Csr K, ivec gids, dvec tv, int32_t nrows) {
+  K_ = std::move(K); gids_ = std::move(gids); tv_ = std::move(tv); nrows_ = nrows;
+  HYMLS_CHECK((int)gids_.size() == K_.n && nrows_ <= K_.n, -2, "level: inconsistent sizes");
+  tv_.resize(K_.n, 1.0);
+}
+
+// which subdomains live here.  One rank: all of them.  Sharded: the subdomains whose reference
+// corner lies in this rank's box of the grid (the boxes of CreatePIDMap, reference
+// src/HYMLS_BasePartitioner.cpp:361-586), plus the halo of subdomains of other ranks that share a
+// separator node with them (needed for the ownership rule "first subdomain that lists the group",
+// src/HYMLS_HierarchicalMap.cpp:261-271, for the A22 multiplicities and for the Schur contributions).
+void LevelSolver::partition(const ivec* level_gids) {
+  if (partitioned_) return;
+  const int nsd = num_subdomains(p_);
+  const bool dist = comm_->distributed();
+  std::vector<char> present;
+  if (level_gids) { present.assign(ngid_, 0); for (int32_t g : *level_gids) present[g] = 1; }
+  sd_rank_.assign(nsd, 0);
+  std::vector<char> cand;
+  if (dist) {
+    cand.assign(nsd, 0);
+    const int bx = (p_.nx + comm_->px - 1) / comm_->px, by = (p_.ny + comm_->py - 1) / comm_->py,
+              bz = (p_.nz + comm_->pz - 1) / comm_->pz;
+    const int rx = comm_->rank % comm_->px, ry = (comm_->rank / comm_->px) % comm_->py, rz = comm_->rank / (comm_->px * comm_->py);
+    const int mx = 2 * p_.sx + 3, my = 2 * p_.sy + 3, mz = 2 * p_.sz + 3;
+    for (int s = 0; s < nsd; s++) {
+      int x, y, z;
+      sd_position(p_, s, x, y, z);
+      const int cx = std::min(std::max(x, 0), p_.nx - 1), cy = std::min(std::max(y, 0), p_.ny - 1),
+                cz = std::min(std::max(z, 0), p_.nz - 1);
+      sd_rank_[s] = ((cz / bz) * comm_->py + cy / by) * comm_->px + cx / bx;
+      cand[s] = nsd <= 4096 || (x >= rx * bx - mx && x < (rx + 1) * bx + mx && y >= ry * by - my && y < (ry + 1) * by + my &&
+                                z >= rz * bz - mz && z < (rz + 1) * bz + mz);
+    }
+  }
+  hm_ = build_hiermap(p_, level_gids ? &present : nullptr, dist ? &cand : nullptr);
+  my_sds_.clear(); halo_sds_.clear();
+  for (int s = 0; s < nsd; s++) if (sd_rank_[s] == comm_->rank) my_sds_.push_back(s);
+  if (dist) {
+    std::vector<char> mark(ngid_, 0);
+    for (int s : my_sds_) for (auto& g : hm_.sd[s].groups) for (int32_t x : g.nodes) mark[x] = 1;
+    for (int s = 0; s < nsd; s++) {
+      if (!cand[s] || sd_rank_[s] == comm_->rank) continue;
+      bool touches = false;
+      for (auto& g : hm_.sd[s].groups) { for (int32_t x : g.nodes) if (mark[x]) { touches = true; break; } if (touches) break; }
+      if (touches) halo_sds_.push_back(s);
+      else hm_.sd[s] = Subdomain();
+    }
+  }
+  partitioned_ = true;
+}
+
+ivec LevelSolver::required_gids() const {
+  ivec r;
+  for (int s : my_sds_) {
+    const Subdomain& S = hm_.sd[s];
+    r.insert(r.end(), S.interior.begin(), S.interior.end());
+    for (auto& g : S.groups) r.insert(r.end(), g.nodes.begin(), g.nodes.end());
+  }
+  std::sort(r.begin(), r.end());
+  r.erase(std::unique(r.begin(), r.end()), r.end());
+  return r;
+}
+
+// keep the rows this rank needs, turn everything else it references into ghost columns
+void LevelSolver::localize() {
+  ivec req = required_gids();
+  std::vector<char> need(ngid_, 0);
+  for (int32_t g : req) need[g] = 1;
+  ivec rows, rp(1, 0), cg;
+  dvec va, tv;
+  keep_entries_.clear();
+  given_nnz_ = K_.val.size();
+  for (int i = 0; i < nrows_; i++) {
+    if (!need[gids_[i]]) continue;
+    need[gids_[i]] = 2;
+    rows.push_back(gids_[i]);
+    tv.push_back(tv_[i]);
+    for (int e = K_.rowptr[i]; e < K_.rowptr[i + 1]; e++) { cg.push_back(gids_[K_.col[e]]); va.push_back(K_.val[e]); keep_entries_.push_back(e); }
+    rp.push_back((int32_t)cg.size());
+  }
+  for (int32_t g : req) HYMLS_CHECK(need[g] == 2, -2, "rank " + std::to_string(comm_->rank) + " was not given the row of gid " +
+                                                          std::to_string(g) + " (see hymls_mi_required_rows)");
+  Csr K; ivec gids;
+  make_local_csr((int64_t)rows.size(), rows.data(), rp.data(), cg.data(), va.data(), ngid_, K, gids);
+  nrows_ = (int32_t)rows.size();
+  K_ = std::move(K); gids_ = std::move(gids);
+  tv.resize(K_.n, 1.0);
+  tv_ = std::move(tv);
+}
+
 void LevelSolver::initialize() {
+  const bool dist = comm_->distributed();
+  if (level_ == 0) partition(nullptr);
+  else { ivec lg(gids_.begin(), gids_.begin() + nrows_); partition(&lg); }
+  if (dist) localize();
   const int n = K_.n;
   HYMLS_CHECK((int)gids_.size() == n && (int)tv_.size() == n, -2, "level: inconsistent sizes");
   g2l_.assign(ngid_, -1);
   for (int i = 0; i < n; i++) g2l_[gids_[i]] = i;
-  std::vector<char> present;
-  const bool all = (int64_t)n == ngid_;
-  if (!all) { present.assign(ngid_, 0); for (int32_t g : gids_) present[g] = 1; }
-  hm_ = build_hiermap(p_, all ? nullptr : &present);
-  // separator numbering (map2 = owned groups of sd 0, sd 1, ...)
+  // separator numbering: owned groups of this rank's subdomains (sd 0, sd 1, ...: map2 of the reference),
+  // then the groups of its subdomains that another rank owns (ghosts)
   pos2_.assign(n, -1);
   intidx_.assign(n, -1);
   sep_row_.clear();
   gptr_.assign(1, 0);
-  for (auto& S : hm_.sd)
+  for (int s : my_sds_) {
+    const Subdomain& S = hm_.sd[s];
     for (int gi : S.owned) {
       for (int32_t g : S.groups[gi].nodes) {
         const int r = g2l_[g];
-        HYMLS_CHECK(r >= 0 && pos2_[r] < 0, -3, "separator node listed twice or missing");
+        HYMLS_CHECK(r >= 0 && r < nrows_ && pos2_[r] < 0, -3, "separator node listed twice or missing");
         pos2_[r] = (int32_t)sep_row_.size();
         sep_row_.push_back(r);
       }
       gptr_.push_back((int32_t)sep_row_.size());
     }
+  }
   n2_ = (int32_t)sep_row_.size();
+  // ghost separators and who owns them
+  std::vector<std::vector<int64_t>> want_sep(comm_->size);
+  std::vector<ivec> dst_sep(comm_->size);
+  if (dist) {
+    std::unordered_map<int32_t, int32_t> first_lister;   // first node of a group -> first subdomain listing it
+    for (int s = 0; s < (int)hm_.sd.size(); s++)
+      for (int gi : hm_.sd[s].owned) first_lister.emplace(hm_.sd[s].groups[gi].nodes[0], s);
+    for (int s : my_sds_)
+      for (auto& g : hm_.sd[s].groups) {
+        const int r0 = g2l_[g.nodes[0]];
+        HYMLS_CHECK(r0 >= 0, -3, "separator node without a row");
+        if (pos2_[r0] >= 0) continue;
+        auto it = first_lister.find(g.nodes[0]);
+        HYMLS_CHECK(it != first_lister.end() && sd_rank_[it->second] != comm_->rank, -3, "separator group without owner");
+        const int q = sd_rank_[it->second];
+        for (int32_t x : g.nodes) {
+          const int r = g2l_[x];
+          HYMLS_CHECK(r >= 0 && r < nrows_ && pos2_[r] < 0, -3, "ghost separator node listed twice or missing");
+          pos2_[r] = (int32_t)sep_row_.size();
+          want_sep[q].push_back(x);
+          dst_sep[q].push_back((int32_t)sep_row_.size());
+          sep_row_.push_back(r);
+        }
+      }
+  }
+  ngs_ = (int32_t)sep_row_.size() - n2_;
   direct_schur_ = level_ >= p_.levels;
   build_classes();
-  HYMLS_CHECK(n1_ + n2_ == n, -3, "partition does not cover the map exactly once");
-  // A12 / A21 in internal numbering
+  // owned rows = layout of the vectors handed to apply_inverse (order of the rows as they were given)
+  {
+    ivec user(n, -1);
+    owned_gids_.clear();
+    for (int i = 0; i < nrows_; i++)
+      if (intidx_[i] >= 0 || (pos2_[i] >= 0 && pos2_[i] < n2_)) { user[i] = (int32_t)owned_gids_.size(); owned_gids_.push_back(gids_[i]); }
+    HYMLS_CHECK((int)owned_gids_.size() == n1_ + n2_, -3, "partition does not cover the map exactly once");
+    if (!dist) HYMLS_CHECK(n1_ + n2_ == n, -3, "partition does not cover the map exactly once");
+    for (int t = 0; t < n1_ + n2_; t++) in_perm_[t] = user[in_perm_[t]];
+    global_n_ = comm_->allsum(n1_ + n2_);
+    global_n2_ = comm_->allsum(n2_);
+  }
+  // A12 (interior rows x separators incl. ghosts) / A21 (owned separator rows x interiors incl. ghosts)
+  ivec node_sd;     // local node -> halo subdomain holding it as interior
+  if (dist) {
+    node_sd.assign(n, -1);
+    for (int s : halo_sds_) for (int32_t x : hm_.sd[s].interior) if (g2l_[x] >= 0) node_sd[g2l_[x]] = s;
+  }
+  ivec row_of_internal(n1_);
+  for (int i = 0; i < n; i++) if (intidx_[i] >= 0) row_of_internal[intidx_[i]] = i;
   a12_row_.assign(n1_ + 1, 0); a21_row_.assign(n2_ + 1, 0);
   a12_col_.clear(); a12_src_.clear(); a21_col_.clear(); a21_src_.clear();
   for (int t = 0; t < n1_; t++) {
-    const int r = in_perm_[t];
+    const int r = row_of_internal[t];
     for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
       const int c = K_.col[e];
       if (pos2_[c] >= 0) { a12_col_.push_back(pos2_[c]); a12_src_.push_back(e); }
     }
     a12_row_[t + 1] = (int32_t)a12_col_.size();
   }
+  std::vector<std::vector<int64_t>> want_int(comm_->size);
+  std::vector<ivec> dst_int(comm_->size);
+  ivec ghost_idx(dist ? n : 0, -1);
+  ngi_ = 0;
   for (int k = 0; k < n2_; k++) {
     const int r = sep_row_[k];
     for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
       const int c = K_.col[e];
       if (intidx_[c] >= 0) { a21_col_.push_back(intidx_[c]); a21_src_.push_back(e); }
+      else if (dist && pos2_[c] < 0 && node_sd[c] >= 0) {
+        if (ghost_idx[c] < 0) {
+          ghost_idx[c] = n1_ + ngi_++;
+          const int q = sd_rank_[node_sd[c]];
+          want_int[q].push_back(gids_[c]);
+          dst_int[q].push_back(ghost_idx[c]);
+        }
+        a21_col_.push_back(ghost_idx[c]); a21_src_.push_back(e);
+      }
     }
     a21_row_[k + 1] = (int32_t)a21_col_.size();
+  }
+  if (dist) {
+    // x1 of the neighbours' interiors next to separators owned here; x2 of the separators owned elsewhere
+    xch_int_.build(*comm_, want_int, dst_int, [&](int64_t g) { const int l = g2l_[g]; return l >= 0 ? intidx_[l] : -1; });
+    xch_sep_.build(*comm_, want_sep, dst_sep, [&](int64_t g) { const int l = g2l_[g]; return (l >= 0 && pos2_[l] < n2_) ? pos2_[l] : -1; });
   }
   build_schur_setup();
   // device residents
   d_krow_ = dev::upload(K_.rowptr); d_kcol_ = dev::upload(K_.col);
   d_kval_ = (double*)dev::alloc(std::max<size_t>(1, K_.val.size()) * sizeof(double));
   d_inperm_ = dev::upload(in_perm_);
-  d_z_ = (double*)dev::alloc((size_t)std::max(n, 1) * sizeof(double));
+  d_z_ = (double*)dev::alloc((size_t)std::max(n1_ + ngi_ + n2_, 1) * sizeof(double));
   d_t1_ = (double*)dev::alloc((size_t)std::max(n1_, 1) * sizeof(double));
-  d_t2_ = (double*)dev::alloc((size_t)std::max(n2_, 1) * sizeof(double));
+  d_t2_ = (double*)dev::alloc((size_t)std::max(n2_ + ngs_, 1) * sizeof(double));
   d_y2_ = (double*)dev::alloc((size_t)std::max(n2_, 1) * sizeof(double));
   d_yb_ = (double*)dev::alloc((size_t)std::max(n2_, 1) * sizeof(double));
   d_a12_row_ = dev::upload(a12_row_); d_a12_col_ = dev::upload(a12_col_); d_a12_src_ = dev::upload(a12_src_);
@@ -349,13 +531,15 @@ void LevelSolver::initialize() {
 void LevelSolver::build_classes() {
   const int n = K_.n;
   const int nsd = (int)hm_.sd.size();
-  // subdomains listing each separator node (for the A22 multiplicities)
-  ivec cnt(n2_ + 1, 0);
-  for (auto& S : hm_.sd) for (auto& g : S.groups) for (int32_t x : g.nodes) cnt[pos2_[g2l_[x]] + 1]++;
-  for (int i = 0; i < n2_; i++) cnt[i + 1] += cnt[i];
-  ivec sdl(cnt[n2_]), fill(cnt.begin(), cnt.end() - 1);
+  const int nsep = n2_ + ngs_;
+  auto sidx = [&](int32_t gid) { const int l = g2l_[gid]; return l >= 0 ? pos2_[l] : -1; };
+  // subdomains (of any rank) listing each separator node (for the A22 multiplicities)
+  ivec cnt(nsep + 1, 0);
+  for (auto& S : hm_.sd) for (auto& g : S.groups) for (int32_t x : g.nodes) { const int k = sidx(x); if (k >= 0) cnt[k + 1]++; }
+  for (int i = 0; i < nsep; i++) cnt[i + 1] += cnt[i];
+  ivec sdl(cnt[nsep]), fill(cnt.begin(), cnt.end() - 1);
   for (int s = 0; s < nsd; s++)
-    for (auto& g : hm_.sd[s].groups) for (int32_t x : g.nodes) sdl[fill[pos2_[g2l_[x]]]++] = s;
+    for (auto& g : hm_.sd[s].groups) for (int32_t x : g.nodes) { const int k = sidx(x); if (k >= 0) sdl[fill[k]++] = s; }
   auto common = [&](int a, int b) {
     int c = 0;
     for (int i = cnt[a]; i < cnt[a + 1]; i++) for (int j = cnt[b]; j < cnt[b + 1]; j++) c += sdl[i] == sdl[j];
@@ -374,13 +558,13 @@ void LevelSolver::build_classes() {
   ivec loc(n, -1);
   std::unordered_map<uint64_t, std::vector<int>> table;
   n1_ = 0;
-  in_perm_.assign(n, -1);
-  for (int s = 0; s < nsd; s++) {
+  in_perm_.clear();
+  for (int s : my_sds_) {
     const Subdomain& S = hm_.sd[s];
     LocalPattern lp;
     lp.nI = (int32_t)S.interior.size();
     lp.nS = S.num_sep();
-    ivec ext_rows;  // level rows of the extended local numbering
+    ivec ext_rows;  // local nodes of the extended local numbering
     ext_rows.reserve(lp.nI + lp.nS);
     for (int32_t g : S.interior) ext_rows.push_back(g2l_[g]);
     ivec lgptr(1, 0), key_extra;
@@ -392,7 +576,7 @@ void LevelSolver::build_classes() {
     for (auto& L : S.linked) { key_extra.push_back(-7); key_extra.insert(key_extra.end(), L.begin(), L.end()); }
     const int ne = lp.nI + lp.nS;
     for (int i = 0; i < ne; i++) {
-      HYMLS_CHECK(ext_rows[i] >= 0 && loc[ext_rows[i]] < 0, -3, "node listed twice in a subdomain");
+      HYMLS_CHECK(ext_rows[i] >= 0 && ext_rows[i] < nrows_ && loc[ext_rows[i]] < 0, -3, "node listed twice in a subdomain or without a row");
       loc[ext_rows[i]] = i;
     }
     lp.rowptr.assign(ne + 1, 0);
@@ -459,22 +643,43 @@ void LevelSolver::build_classes() {
     C.lu.h_src.insert(C.lu.h_src.end(), src.begin(), src.end());
     for (int t = 0; t < C.pat.nI; t++) {
       const int r = g2l_[S.interior[C.lu.plan.perm[t]]];
-      in_perm_[n1_ + t] = r;
+      in_perm_.push_back(r);
       intidx_[r] = n1_ + t;
     }
     n1_ += C.pat.nI;
   }
-  for (int k = 0; k < n2_; k++) in_perm_[n1_ + k] = sep_row_[k];
+  for (int k = 0; k < n2_; k++) in_perm_.push_back(sep_row_[k]);
   if (std::getenv("HYMLS_MI_VERBOSE")) {
-    std::fprintf(stderr, "[hymls_mi] level %d: n %d subdomains %d classes %zu n1 %d n2 %d\n", level_, n, nsd, cls_.size(), n1_, n2_);
+    std::fprintf(stderr, "[hymls_mi] rank %d level %d: local nodes %d subdomains %zu (+%zu halo) classes %zu n1 %d n2 %d ghost sep %d\n",
+                 comm_->rank, level_, n, my_sds_.size(), halo_sds_.size(), cls_.size(), n1_, n2_, ngs_);
     size_t shown = 0;
     for (auto& c : cls_) if (shown++ < 4 || c->lu.members.size() > 50) print_plan_stats(c->lu.plan, "  class", (int)c->lu.members.size());
   }
 }
 
+// what is kept of one subdomain's (transformed) separator block, as laid out in its extraction
+// record: the V-sum x V-sum part (ngl x ngl, column-major) followed by one dense block per linked
+// set with at least one non-V-sum row.  Depends on the group structure only, so a rank can lay out
+// the records it receives from its neighbours.
+LevelSolver::ExtLayout LevelSolver::ext_layout(const Subdomain& S) const {
+  ExtLayout L;
+  if (direct_schur_) { const int64_t nS = S.num_sep(); L.size = nS * nS; return L; }
+  L.ngl = (int32_t)S.groups.size();
+  int64_t off = (int64_t)L.ngl * L.ngl;
+  for (auto& ls : S.linked) {
+    int32_t len = 0;
+    for (int gi : ls) len += (int32_t)S.groups[gi].nodes.size() - 1;
+    L.blk_len.push_back(len);
+    L.blk_off.push_back(len ? off : -1);
+    off += (int64_t)len * len;
+  }
+  L.size = off;
+  return L;
+}
+
 void LevelSolver::build_schur_setup() {
-  const int nsd = (int)hm_.sd.size();
-  const int ng_total = (int)gptr_.size() - 1;
+  const bool dist = comm_->distributed();
+  const int ng_owned = (int)gptr_.size() - 1;
   // ---- per class: what to keep of the (transformed) separator block
   ext_total_ = 0;
   for (auto& cp : cls_) {
@@ -505,26 +710,83 @@ void LevelSolver::build_schur_setup() {
       for (auto& g : S.groups) for (int32_t x : g.nodes) C.tvloc[b * nS + t++] = tv_[g2l_[x]];
     }
   }
+  ext_recv_base_ = ext_total_;
+  // owned group lookup by first gid
+  std::unordered_map<int32_t, int32_t> gidx_of_first;
+  {
+    int g = 0;
+    for (int s : my_sds_) for (int gi : hm_.sd[s].owned) gidx_of_first[hm_.sd[s].groups[gi].nodes[0]] = g++;
+  }
+  auto owned_sep = [&](int32_t gid) { const int l = g2l_[gid]; return (l >= 0 && pos2_[l] >= 0 && pos2_[l] < n2_) ? pos2_[l] : -1; };
+  // ---- records of the neighbours' subdomains that touch separators owned here
+  std::vector<std::pair<int, int64_t>> contributors;   // (subdomain, base of its record in the extraction buffer)
+  for (int s : my_sds_) contributors.emplace_back(s, cls_[sd_cls_[s]]->ext_base + (int64_t)sd_bidx_[s] * cls_[sd_cls_[s]]->ext_size);
+  if (dist) {
+    std::vector<std::vector<int64_t>> want(comm_->size);
+    std::vector<std::vector<int64_t>> want_len(comm_->size);
+    std::vector<std::pair<int, int64_t>> halo_list;
+    for (int q = 0; q < comm_->size; q++) {
+      for (int t : halo_sds_) {
+        if (sd_rank_[t] != q) continue;
+        const Subdomain& T = hm_.sd[t];
+        bool mine = false;
+        for (auto& g : T.groups) {
+          if (direct_schur_) { for (int32_t x : g.nodes) if (owned_sep(x) >= 0) { mine = true; break; } }
+          else mine = gidx_of_first.count(g.nodes[0]) > 0;
+          if (mine) break;
+        }
+        if (!mine) continue;
+        const int64_t len = ext_layout(T).size;
+        want[q].push_back(t);
+        want_len[q].push_back(len);
+        halo_list.emplace_back(t, ext_total_);
+        ext_total_ += len;
+      }
+    }
+    auto asked = comm_->exchange_lists(want);
+    auto asked_len = comm_->exchange_lists(want_len);
+    rec_send_.clear();
+    rec_scnt_.assign(comm_->size, 0); rec_rcnt_.assign(comm_->size, 0);
+    rec_nsend_ = 0; rec_nrecv_ = ext_total_ - ext_recv_base_;
+    for (int q = 0; q < comm_->size; q++) {
+      for (int64_t l : want_len[q]) rec_rcnt_[q] += l;
+      for (size_t k = 0; k < asked[q].size(); k++) {
+        const int s = (int)asked[q][k];
+        HYMLS_CHECK(s >= 0 && s < (int)hm_.sd.size() && sd_rank_[s] == comm_->rank && sd_cls_[s] >= 0, -3,
+                    "a neighbour asked for the Schur record of a subdomain that does not live here");
+        const Cls& C = *cls_[sd_cls_[s]];
+        HYMLS_CHECK(C.ext_size == asked_len[q][k], -3, "Schur record laid out differently on two ranks");
+        rec_send_.push_back({C.ext_base + (int64_t)sd_bidx_[s] * C.ext_size, C.ext_size});
+        rec_scnt_[q] += C.ext_size;
+        rec_nsend_ += C.ext_size;
+      }
+    }
+    rec_any_ = comm_->allsum(rec_nsend_) > 0;
+    if (rec_any_) { comm_->send_arena(rec_nsend_); comm_->recv_arena(rec_nrecv_); }
+    std::sort(halo_list.begin(), halo_list.end());
+    contributors.insert(contributors.end(), halo_list.begin(), halo_list.end());
+    std::sort(contributors.begin(), contributors.end());   // subdomain order, as on one rank
+  }
   // ---- pull lists
-  std::vector<std::pair<int64_t, int64_t>> coo;
+  struct Coo { int64_t row, colgid, src; };
+  std::vector<Coo> coo;
   if (direct_schur_) {
     red_.n = n2_;
-    for (int s = 0; s < nsd; s++) {
-      const Subdomain& S = hm_.sd[s];
-      const Cls& C = *cls_[sd_cls_[s]];
-      const int nS = C.pat.nS;
-      ivec gp;
-      for (auto& g : S.groups) for (int32_t x : g.nodes) gp.push_back(pos2_[g2l_[x]]);
-      const int64_t base = C.ext_base + (int64_t)sd_bidx_[s] * C.ext_size;
+    for (auto& ct : contributors) {
+      const Subdomain& S = hm_.sd[ct.first];
+      const int nS = S.num_sep();
+      ivec gp, gg;
+      for (auto& g : S.groups) for (int32_t x : g.nodes) { gp.push_back(owned_sep(x)); gg.push_back(x); }
       for (int b = 0; b < nS; b++)
-        for (int a = 0; a < nS; a++) coo.emplace_back((int64_t)gp[a] * n2_ + gp[b], base + a + (int64_t)nS * b);
+        for (int a = 0; a < nS; a++)
+          if (gp[a] >= 0) coo.push_back({gp[a], gg[b], ct.second + a + (int64_t)nS * b});
     }
   } else {
     // Householder rows (InitializeOT, reference src/HYMLS_SchurPreconditioner.cpp:384-467 +
     // Householder::Construct, src/HYMLS_Householder.cpp:128-163)
     otw_.assign(n2_, 0.0);
-    vs_.resize(ng_total);
-    for (int g = 0; g < ng_total; g++) {
+    vs_.resize(ng_owned);
+    for (int g = 0; g < ng_owned; g++) {
       const int b = gptr_[g], e = gptr_[g + 1];
       vs_[g] = b;
       dvec v(e - b);
@@ -540,16 +802,10 @@ void LevelSolver::build_schur_setup() {
       if (nrm2 < SMALL_ENTRY) continue;  // no row in T: the transform acts as -I (reference quirk)
       for (int i = b; i < e; i++) otw_[i] = v[i - b] / nrm2;
     }
-    // owned group lookup by first gid
-    std::unordered_map<int32_t, int32_t> gidx_of_first;
-    {
-      int g = 0;
-      for (auto& S : hm_.sd) for (int gi : S.owned) gidx_of_first[S.groups[gi].nodes[0]] = g++;
-    }
     // dense blocks: one per owned linked set with at least one non-V-sum row
     std::map<int32_t, int> bc_of_size;
     std::unordered_map<int32_t, std::pair<int, int>> block_of_key;  // first group's vsum gid -> (class, index)
-    for (int s = 0; s < nsd; s++) {
+    for (int s : my_sds_) {
       const Subdomain& S = hm_.sd[s];
       for (auto& L : S.owned_linked) {
         ivec ids;
@@ -565,34 +821,39 @@ void LevelSolver::build_schur_setup() {
     }
     std::vector<std::vector<std::vector<int64_t>>> contrib(blocks_.size());
     for (size_t c = 0; c < blocks_.size(); c++) contrib[c].resize(blocks_[c].nblk);
-    red_.n = ng_total;
-    for (int s = 0; s < nsd; s++) {
-      const Subdomain& S = hm_.sd[s];
-      const Cls& C = *cls_[sd_cls_[s]];
-      const int64_t base = C.ext_base + (int64_t)sd_bidx_[s] * C.ext_size;
-      ivec vg(C.ngl);
-      for (int a = 0; a < C.ngl; a++) {
+    red_.n = ng_owned;
+    for (auto& ct : contributors) {
+      const Subdomain& S = hm_.sd[ct.first];
+      const bool local = sd_rank_[ct.first] == comm_->rank;
+      const ExtLayout L = ext_layout(S);
+      const int64_t base = ct.second;
+      ivec vg(L.ngl);
+      for (int a = 0; a < L.ngl; a++) {
         auto it = gidx_of_first.find(S.groups[a].nodes[0]);
-        HYMLS_CHECK(it != gidx_of_first.end(), -3, "separator group without owner");
-        vg[a] = it->second;
-        HYMLS_CHECK(gptr_[vg[a] + 1] - gptr_[vg[a]] == (int)S.groups[a].nodes.size(), -3, "group differs between subdomains");
+        HYMLS_CHECK(dist || it != gidx_of_first.end(), -3, "separator group without owner");
+        vg[a] = it != gidx_of_first.end() ? it->second : -1;
+        if (vg[a] >= 0)
+          HYMLS_CHECK(gptr_[vg[a] + 1] - gptr_[vg[a]] == (int)S.groups[a].nodes.size(), -3, "group differs between subdomains");
       }
-      for (int b = 0; b < C.ngl; b++)
-        for (int a = 0; a < C.ngl; a++) coo.emplace_back((int64_t)vg[a] * ng_total + vg[b], base + a + (int64_t)C.ngl * b);
+      for (int b = 0; b < L.ngl; b++)
+        for (int a = 0; a < L.ngl; a++)
+          if (vg[a] >= 0) coo.push_back({vg[a], S.groups[b].nodes[0], base + a + (int64_t)L.ngl * b});
       for (size_t li = 0; li < S.linked.size(); li++) {
-        if (C.blk_off[li] < 0) continue;
+        if (L.blk_off[li] < 0) continue;
         auto it = block_of_key.find(S.groups[S.linked[li][0]].nodes[0]);
-        HYMLS_CHECK(it != block_of_key.end(), -3, "linked separator set without owner");
+        HYMLS_CHECK(dist || it != block_of_key.end(), -3, "linked separator set without owner");
+        if (it == block_of_key.end()) continue;   // eliminated on another rank
         BlockClass& B = blocks_[it->second.first];
-        HYMLS_CHECK(B.nb == C.blk_len[li], -3, "linked separator set differs between subdomains");
+        HYMLS_CHECK(B.nb == L.blk_len[li], -3, "linked separator set differs between subdomains");
         // same node order as the owner's block?
         size_t t = 0;
         for (int gi : S.linked[li])
           for (size_t q = 1; q < S.groups[gi].nodes.size(); q++, t++)
             HYMLS_CHECK(B.ids[(size_t)it->second.second * B.nb + t] == pos2_[g2l_[S.groups[gi].nodes[q]]], -3,
                         "linked separator set ordered differently between subdomains");
-        contrib[it->second.first][it->second.second].push_back(base + C.blk_off[li]);
+        contrib[it->second.first][it->second.second].push_back(base + L.blk_off[li]);
       }
+      (void)local;
     }
     for (size_t c = 0; c < blocks_.size(); c++) {
       BlockClass& B = blocks_[c];
@@ -603,21 +864,24 @@ void LevelSolver::build_schur_setup() {
       B.d_binv = (double*)dev::alloc((size_t)B.nb * B.nb * B.nblk * sizeof(double));
     }
     d_gptr_ = dev::upload(gptr_); d_otw_ = dev::upload(otw_); d_vs_ = dev::upload(vs_);
-    d_vrhs_ = (double*)dev::alloc((size_t)std::max(ng_total, 1) * sizeof(double));
-    d_vsol_ = (double*)dev::alloc((size_t)std::max(ng_total, 1) * sizeof(double));
+    d_vrhs_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
+    d_vsol_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
   }
-  // COO -> CSR pattern with pull lists
-  std::sort(coo.begin(), coo.end());
+  // COO -> CSR pattern (columns = gids) with pull lists
+  std::sort(coo.begin(), coo.end(), [](const Coo& a, const Coo& b) {
+    if (a.row != b.row) return a.row < b.row;
+    if (a.colgid != b.colgid) return a.colgid < b.colgid;
+    return a.src < b.src;
+  });
   const int64_t nr = red_.n;
   red_.rowptr.assign(nr + 1, 0); red_.col.clear();
   red_pull_ptr_.assign(1, 0); red_pull_idx_.clear();
   red_pull_idx_.reserve(coo.size());
   for (size_t k = 0; k < coo.size();) {
     size_t k2 = k;
-    while (k2 < coo.size() && coo[k2].first == coo[k].first) { red_pull_idx_.push_back(coo[k2].second); k2++; }
-    const int64_t r = coo[k].first / nr, c = coo[k].first % nr;
-    red_.col.push_back((int32_t)c);
-    red_.rowptr[r + 1]++;
+    while (k2 < coo.size() && coo[k2].row == coo[k].row && coo[k2].colgid == coo[k].colgid) { red_pull_idx_.push_back(coo[k2].src); k2++; }
+    red_.col.push_back((int32_t)coo[k].colgid);
+    red_.rowptr[coo[k].row + 1]++;
     red_pull_ptr_.push_back((int64_t)red_pull_idx_.size());
     k = k2;
   }
@@ -655,22 +919,112 @@ void LevelSolver::build_schur_setup() {
   }
   n_fsubs_ = (int32_t)subs.size();
   if (std::getenv("HYMLS_MI_VERBOSE"))
-    std::fprintf(stderr, "[hymls_mi] level %d: fused interior solve for %d of %zu subdomains, LDS %d doubles (%.1f KiB)\n", level_, n_fsubs_, hm_.sd.size(), fused_lds_, fused_lds_ * 8.0 / 1024);
+    std::fprintf(stderr, "[hymls_mi] rank %d level %d: fused interior solve for %d of %zu subdomains, LDS %d doubles (%.1f KiB)\n",
+                 comm_->rank, level_, n_fsubs_, my_sds_.size(), fused_lds_, fused_lds_ * 8.0 / 1024);
   d_fplans_ = dev::upload(plans);
   d_fsubs_ = dev::upload(subs);
 }
 
+// the extraction records of boundary subdomains travel to the ranks that own some of their separators
+// (the Export with SumInto of the reference's SchurComplement::Construct, src/HYMLS_SchurComplement.cpp:195-260;
+// here the owner pulls, in subdomain order, so the sums are formed in the same order as on one rank)
+void LevelSolver::exchange_records() {
+  if (!rec_any_) return;
+  double* sb = comm_->send_arena(rec_nsend_);
+  double* rb = comm_->recv_arena(rec_nrecv_);
+  int64_t off = 0;
+  for (auto& sg : rec_send_) { dev::d2d(sb + off, d_ext_ + sg.off, (size_t)sg.len * sizeof(double)); off += sg.len; }
+  const int ierr = comm_->alltoallv(comm_->ctx, sb, rec_scnt_.data(), rb, rec_rcnt_.data(), (int32_t)sizeof(double), 1);
+  HYMLS_CHECK(ierr == 0, -3, "device all-to-all failed in the transport callback");
+  if (rec_nrecv_) dev::d2d(d_ext_ + ext_recv_base_, rb, (size_t)rec_nrecv_ * sizeof(double));
+}
+
 void LevelSolver::set_values(const dvec& val) {
+  if (comm_->distributed() && initialized_) {   // values of the rows as they were given; keep the local ones
+    HYMLS_CHECK(val.size() == given_nnz_, -2, "SetMatrix: pattern changed");
+    for (size_t i = 0; i < keep_entries_.size(); i++) K_.val[i] = val[keep_entries_[i]];
+    return;
+  }
   HYMLS_CHECK(val.size() == K_.val.size(), -2, "SetMatrix: pattern changed");
   K_.val = val;
 }
 
+// the reduced matrix of all ranks: every rank contributes the rows it owns; rows in rank order,
+// columns turned into global row numbers and sorted.  On one rank this is just red_.
+void LevelSolver::assemble_reduced(Csr& R, ivec& row_gids, dvec* tvn) {
+  if (!glob_ready_) {
+    ivec my_gids(red_.n);
+    if (direct_schur_) for (int k = 0; k < n2_; k++) my_gids[k] = gids_[sep_row_[k]];
+    else for (int g = 0; g < red_.n; g++) my_gids[g] = gids_[sep_row_[vs_[g]]];
+    ivec my_len(red_.n);
+    for (int r = 0; r < red_.n; r++) my_len[r] = red_.rowptr[r + 1] - red_.rowptr[r];
+    std::vector<int64_t> cnt;
+    glob_gids_ = comm_->allgather(my_gids, &cnt);
+    glob_row_off_.assign(1, 0);
+    for (int64_t c : cnt) glob_row_off_.push_back(glob_row_off_.back() + c);
+    ivec len = comm_->allgather(my_len);
+    ivec colg = comm_->allgather(red_.col);
+    if (tvn) glob_tv_ = comm_->allgather(*tvn);
+    const int64_t N = (int64_t)glob_gids_.size();
+    HYMLS_CHECK(N < (int64_t)1 << 31, -2, "reduced matrix too large for 32-bit row numbers");
+    std::unordered_map<int32_t, int32_t> row_of;
+    row_of.reserve((size_t)N * 2);
+    for (int64_t i = 0; i < N; i++) HYMLS_CHECK(row_of.emplace(glob_gids_[i], (int32_t)i).second, -3, "separator owned by two ranks");
+    glob_.n = (int32_t)N;
+    glob_.rowptr.assign(N + 1, 0);
+    for (int64_t i = 0; i < N; i++) glob_.rowptr[i + 1] = glob_.rowptr[i] + len[i];
+    glob_.col.resize(colg.size());
+    glob_perm_.resize(colg.size());
+    std::vector<std::pair<int32_t, int64_t>> row;
+    for (int64_t i = 0; i < N; i++) {
+      row.clear();
+      for (int64_t e = glob_.rowptr[i]; e < glob_.rowptr[i + 1]; e++) {
+        auto it = row_of.find(colg[e]);
+        HYMLS_CHECK(it != row_of.end(), -3, "reduced matrix refers to a node nobody owns");
+        row.emplace_back(it->second, e);
+      }
+      std::sort(row.begin(), row.end());
+      for (size_t k = 0; k < row.size(); k++) { glob_.col[glob_.rowptr[i] + k] = row[k].first; glob_perm_[row[k].second] = glob_.rowptr[i] + (int64_t)k; }
+    }
+    glob_.val.assign(glob_.col.size(), 0.0);
+    glob_ready_ = true;
+  }
+  dvec vals = comm_->allgather(red_.val);
+  HYMLS_CHECK(vals.size() == glob_.val.size(), -3, "reduced matrix changed its pattern between two Compute calls");
+  for (size_t e = 0; e < vals.size(); e++) glob_.val[glob_perm_[e]] = vals[e];
+  R = glob_;
+  row_gids = glob_gids_;
+}
+
+// vectors between this level's owners of the V-sum nodes and the next level's layout
+void LevelSolver::build_handoff(const ivec& next_owned) {
+  if (!comm_->distributed()) return;
+  std::unordered_map<int32_t, int32_t> row_of;
+  row_of.reserve(glob_gids_.size() * 2);
+  for (size_t i = 0; i < glob_gids_.size(); i++) row_of[glob_gids_[i]] = (int32_t)i;
+  std::vector<std::vector<int64_t>> want(comm_->size);
+  std::vector<ivec> dst(comm_->size);
+  for (size_t k = 0; k < next_owned.size(); k++) {
+    const int64_t i = row_of.at(next_owned[k]);
+    const int q = (int)(std::upper_bound(glob_row_off_.begin(), glob_row_off_.end(), i) - glob_row_off_.begin()) - 1;
+    want[q].push_back(i - glob_row_off_[q]);
+    dst[q].push_back((int32_t)k);
+  }
+  const int64_t nown = red_.n;
+  xch_down_.build(*comm_, want, dst, [nown](int64_t k) { return k < nown ? (int32_t)k : -1; });
+  dev::free(d_nrhs_); dev::free(d_nsol_);
+  d_nrhs_ = (double*)dev::alloc(std::max<size_t>(1, next_owned.size()) * sizeof(double));
+  d_nsol_ = (double*)dev::alloc(std::max<size_t>(1, next_owned.size()) * sizeof(double));
+}
+
 void LevelSolver::compute() {
   HYMLS_CHECK(initialized_, -1, "level not initialized");
+  const bool dist = comm_->distributed();
   dev::h2d(d_kval_, K_.val.data(), K_.val.size() * sizeof(double));
   dev::gather((int64_t)a12_col_.size(), d_a12_src_, d_kval_, d_a12_val_);
   dev::gather((int64_t)a21_col_.size(), d_a21_src_, d_kval_, d_a21_val_);
   // ---- interior factorisations + separator blocks, class by class, chunk by chunk
+  int32_t bad = 0;
   for (auto& cp : cls_) {
     Cls& C = *cp;
     dev::zero(C.lu.batch.flag, sizeof(int32_t));
@@ -684,20 +1038,27 @@ void LevelSolver::compute() {
       dev::sblock_extract(C.pat.nS, C.ext_size, C.d_pick, C.lu.batch.sblock,
                           d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size, C.ext_size, nbc);
     }
-    HYMLS_CHECK(C.lu.check_flag() == 0, -4, "subdomain factorisation hit a zero or non-finite pivot (level " +
-                                                std::to_string(level_) + ")");
+    if (C.lu.check_flag() != 0) bad = 1;
   }
+  // (collective: every rank has to reach the exchanges below, so errors are agreed on first)
+  HYMLS_CHECK(comm_->allsum(bad) == 0, -4, "subdomain factorisation hit a zero or non-finite pivot (level " +
+                                               std::to_string(level_) + ")");
+  exchange_records();
   // ---- assemble what is kept of the Schur complement
   dev::pull_sum((int64_t)red_.col.size(), d_red_pull_ptr_, d_red_pull_idx_, d_ext_, d_red_val_);
   dev::d2h(red_.val.data(), d_red_val_, red_.val.size() * sizeof(double));
   ivec next_gids;
+  Csr G;
   if (direct_schur_) {
     // Preconditioner.cpp:485-500: S assembled, DropByValue (RelZeroDiag), CoarseSolver
-    for (int k = 0; k < n2_; k++) next_gids.push_back(gids_[sep_row_[k]]);
-    Csr S = drop_by_value(red_, SMALL_ENTRY, 1);
+    assemble_reduced(G, next_gids, nullptr);
+    Csr S = drop_by_value(G, SMALL_ENTRY, 1);
     next_.reset();
     next_level_ = nullptr;
-    next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &sep_sd_ptr_, &sep_sd_, &sd_center_));
+    next_is_direct_ = true;
+    if (dist) next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_));
+    else next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &sep_sd_ptr_, &sep_sd_, &sd_center_));
+    build_handoff(next_gids);
     return;
   }
   dev::zero(d_flag_, sizeof(int32_t));
@@ -710,40 +1071,51 @@ void LevelSolver::compute() {
   }
   int32_t flag = 0;
   dev::d2h(&flag, d_flag_, sizeof flag);
-  HYMLS_CHECK(flag == 0, -4,
+  HYMLS_CHECK(comm_->allsum(flag != 0) == 0, -4,
               "singular separator block on level " + std::to_string(level_) +
                   " (3D Stokes-C needs the Skew Cartesian partitioner: isolated pressure 'tubes' on subdomain edges)");
   // ---- next level (ComputeNextLevel, reference src/HYMLS_SchurPreconditioner.cpp:520-629)
-  Csr R = drop_by_value(red_, SMALL_ENTRY, 0);
   const int ng = (int)vs_.size();
-  next_gids.resize(ng);
-  for (int g = 0; g < ng; g++) next_gids[g] = gids_[sep_row_[vs_[g]]];
+  dvec tvn;
+  if (!glob_ready_) {
+    // next test vector = V-sum part of H * testvector (:569-573)
+    tvn.resize(ng);
+    for (int g = 0; g < ng; g++) {
+      double dot = 0;
+      for (int i = gptr_[g]; i < gptr_[g + 1]; i++) dot += otw_[i] * tv_[sep_row_[i]];
+      tvn[g] = 2.0 * otw_[gptr_[g]] * dot - tv_[sep_row_[gptr_[g]]];
+    }
+  }
+  assemble_reduced(G, next_gids, &tvn);
+  Csr R = drop_by_value(G, SMALL_ENTRY, 0);
   if (level_ + 1 < p_.levels) {
+    next_is_direct_ = false;
     if (next_level_ && next_pattern_key_rowptr_ == R.rowptr && next_pattern_key_col_ == R.col) {
-      next_level_->set_values(R.val);
+      next_level_->set_values(R.val);   // (sharded: the next level keeps the rows it needs)
     } else {
-      // next test vector = V-sum part of H * testvector (:569-573)
-      dvec tvn(ng);
-      for (int g = 0; g < ng; g++) {
-        double dot = 0;
-        for (int i = gptr_[g]; i < gptr_[g + 1]; i++) dot += otw_[i] * tv_[sep_row_[i]];
-        tvn[g] = 2.0 * otw_[gptr_[g]] * dot - tv_[sep_row_[gptr_[g]]];
-      }
       next_pattern_key_rowptr_ = R.rowptr; next_pattern_key_col_ = R.col;
-      next_level_ = new LevelSolver(p_.next_level(), level_ + 1, R, next_gids, tvn, ngid_);
+      next_level_ = new LevelSolver(p_.next_level(), level_ + 1, ngid_, comm_);
       next_.reset(next_level_);
+      next_level_->set_rows(R, next_gids, glob_tv_, R.n);
       next_level_->initialize();
+      build_handoff(next_level_->owned_gids());
     }
     next_level_->profiling = false;  // phases are reported for the top level only
     next_level_->compute();
   } else {
     next_level_ = nullptr;
-    ivec cp(1, 0), cl;
-    for (int g = 0; g < ng; g++) {
-      for (int t = sep_sd_ptr_[vs_[g]]; t < sep_sd_ptr_[vs_[g] + 1]; t++) cl.push_back(sep_sd_[t]);
-      cp.push_back((int32_t)cl.size());
+    next_is_direct_ = true;
+    if (dist) {
+      next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_));
+    } else {
+      ivec cp(1, 0), cl;
+      for (int g = 0; g < ng; g++) {
+        for (int t = sep_sd_ptr_[vs_[g]]; t < sep_sd_ptr_[vs_[g] + 1]; t++) cl.push_back(sep_sd_[t]);
+        cp.push_back((int32_t)cl.size());
+      }
+      next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &cp, &cl, &sd_center_));
     }
-    next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &cp, &cl, &sd_center_));
+    build_handoff(next_gids);
   }
 }
 
@@ -753,47 +1125,63 @@ void LevelSolver::interior_solve(double* x1) {
     if (!cls_fused_[c]) cls_[c]->lu.solve(x1);
 }
 
+// rhs/sol: entries of the nodes this rank owns on this level that go on to the next one
+void LevelSolver::next_apply(const double* rhs, double* sol) {
+  if (!comm_->distributed()) { next_->apply_inverse(rhs, sol); return; }
+  xch_down_.forward(rhs, d_nrhs_);
+  next_->apply_inverse(d_nrhs_, d_nsol_);
+  if (next_is_direct_) {
+    // every rank solved the whole coarse system: keep the entries owned here (rows are in rank order)
+    if (red_.n) dev::d2d(sol, d_nsol_ + glob_row_off_[comm_->rank], (size_t)red_.n * sizeof(double));
+  } else {
+    xch_down_.backward(d_nsol_, sol);
+  }
+}
+
 void LevelSolver::schur_apply(double* rhs2, double* x2) {
-  if (n2_ == 0) return;
-  if (direct_schur_) { next_->apply_inverse(rhs2, x2); return; }
+  if (global_n2_ == 0) return;
+  if (direct_schur_) { next_apply(rhs2, x2); return; }
   // SchurPreconditioner::ApplyInverse (reference src/HYMLS_SchurPreconditioner.cpp:1010-1093)
   const int ng = (int)vs_.size();
   dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);                       // B' = H rhs
   for (auto& B : blocks_) dev::blocks_apply(B.nb, B.nblk, B.d_binv, B.d_ids, rhs2, x2);
   dev::gather(ng, d_vs_, rhs2, d_vrhs_);
   if (profiling && level_ == 0) dev::mark(4, true);
-  next_->apply_inverse(d_vrhs_, d_vsol_);
+  next_apply(d_vrhs_, d_vsol_);
   if (profiling && level_ == 0) dev::mark(4, false);
   dev::scatter(ng, d_vs_, d_vsol_, x2);
   dev::ot_apply(ng, d_gptr_, d_otw_, x2);                         // Y = H Y
 }
 
 void LevelSolver::apply_inverse(const double* b, double* x) {
-  HYMLS_CHECK(next_ != nullptr || n2_ == 0, -1, "The preconditioner has not yet been computed.");
+  HYMLS_CHECK(next_ != nullptr || global_n2_ == 0, -1, "The preconditioner has not yet been computed.");
   // Preconditioner::ApplyInverse (reference src/HYMLS_Preconditioner.cpp:930-1070)
-  const int n = K_.n;
-  double* z1 = d_z_;
-  double* z2 = d_z_ + n1_;
+  double* z1 = d_z_;                    // [x1 | x1 of the neighbours next to my separators | x2]
+  double* z2 = d_z_ + n1_ + ngi_;
   if (profiling) dev::mark(0, true);
-  dev::gather(n, d_inperm_, b, d_z_);                       // b1, b2
+  dev::gather(n1_, d_inperm_, b, z1);                       // b1
+  dev::gather(n2_, d_inperm_ + n1_, b, z2);                 // b2
   if (profiling) dev::mark(1, true);
   interior_solve(z1);                                       // x1 = A11 \ b1
   if (profiling) { dev::mark(1, false); dev::mark(2, true); }
+  xch_int_.forward(z1, z1);                                 // halo: interior layer of the neighbouring ranks
   dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1, z2, -1.0, 1.0);  // b2 - A21 x1
   if (profiling) { dev::mark(2, false); dev::mark(3, true); }
   schur_apply(z2, d_t2_);                                   // x2
   if (profiling) { dev::mark(3, false); dev::mark(2, true); }
+  xch_sep_.forward(d_t2_, d_t2_);                           // halo: separators owned by the neighbouring ranks
   dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0);  // y1 = A12 x2
   if (profiling) { dev::mark(2, false); dev::mark(1, true); }
   interior_solve(d_t1_);                                    // A11 \ y1
   if (profiling) dev::mark(1, false);
   dev::axpby(n1_, -1.0, d_t1_, 1.0, z1);                    // x1 -= ...
-  dev::d2d(z2, d_t2_, (size_t)n2_ * sizeof(double));
-  dev::scatter(n, d_inperm_, d_z_, x);
+  dev::scatter(n1_, d_inperm_, z1, x);
+  dev::scatter(n2_, d_inperm_ + n1_, d_t2_, x);
   if (profiling) dev::mark(0, false);
 }
 
 void LevelSolver::matvec(const double* x, double* y) const {
+  HYMLS_CHECK(!comm_->distributed(), -99, "matvec of the sharded operator belongs to the caller (halo exchange of K)");
   dev::spmv(K_.n, d_krow_, d_kcol_, d_kval_, x, y, 1.0, 0.0);
 }
 
@@ -805,7 +1193,7 @@ void LevelSolver::add_stats(ApplyStats& st, bool as_coarse) const {
     sep = 2.0 * 12.0 * n2_;
     for (auto& B : blocks_) sep += (8.0 * B.nb * B.nb + 4.0 * B.nb) * B.nblk;
   }
-  const double N = (double)K_.n;
+  const double N = (double)(n1_ + n2_);
   vec = 8.0 * (4.0 * N + 7.0 * n1_ + 12.0 * n2_);
   if (as_coarse) st.bytes_coarse += f + sp + sep + vec;
   else { st.bytes_factor += f; st.bytes_spmv += sp; st.bytes_sep += sep; st.bytes_vec += vec; }

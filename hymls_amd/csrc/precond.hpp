@@ -11,6 +11,7 @@
 #include "partition.hpp"
 #include "symbolic.hpp"
 #include "device.hpp"
+#include "comm.hpp"
 
 namespace hymls {
 
@@ -73,22 +74,38 @@ class DirectSolver : public Operator {
   int32_t* d_fix_ = nullptr;
 };
 
+// local CSR of a sharded level: `row_gids` rows with global column ids become a square local matrix over
+// the nodes [rows in the given order | ghost columns in ascending gid order] (ghost nodes have empty rows)
+void make_local_csr(int64_t nrows, const int32_t* row_gids, const int32_t* rowptr, const int32_t* col_gids,
+                    const double* val, int64_t ngid, Csr& K, ivec& gids);
+
 class LevelSolver : public Operator {
  public:
-  LevelSolver(const Params& p, int level, Csr K, ivec gids, dvec testvec, int64_t ngid);
+  LevelSolver(const Params& p, int level, int64_t ngid, const Comm* comm);
   ~LevelSolver() override;
+  // subdomains of this rank (+ halo); level_gids: the gids that exist on this level (nullptr: all)
+  void partition(const ivec* level_gids);
+  ivec required_gids() const;           // rows this rank must be given: interiors + separators of its subdomains
+  // K over local nodes: the first nrows nodes have rows (any superset of required_gids()), the others are
+  // ghost columns; on one rank simply the whole matrix
+  void set_rows(Csr K, ivec gids, dvec tv, int32_t nrows);
   void initialize();
   void compute();                       // uses the host values of K (uploads them)
   void set_values(const dvec& val);     // SetMatrix with unchanged pattern
+  // b, x: this rank's owned rows (interiors of its subdomains + separators it owns) in the order of owned_gids()
   void apply_inverse(const double* b, double* x) override;
-  int64_t size() const override { return K_.n; }
+  int64_t size() const override { return global_n_; }
   void add_stats(ApplyStats& st, bool as_coarse) const override;
-  void matvec(const double* x, double* y) const;  // y = K x (level ordering)
+  void matvec(const double* x, double* y) const;  // y = K x (level ordering, one rank only)
 
   // introspection
   const HierMap& hiermap() const { return hm_; }
   int level() const { return level_; }
-  int64_t schur_size() const { return n2_; }
+  int64_t schur_size() const { return global_n2_; }
+  int64_t num_subdomains_global() const { return (int64_t)hm_.sd.size(); }
+  const ivec& owned_gids() const { return owned_gids_; }
+  int64_t num_owned() const { return (int64_t)owned_gids_.size(); }
+  int32_t num_rows() const { return nrows_; }
   Operator* next() const { return next_.get(); }
   LevelSolver* next_level() const { return next_level_; }
   double phase_seconds[5] = {0, 0, 0, 0, 0};
@@ -96,28 +113,52 @@ class LevelSolver : public Operator {
 
  private:
   struct Cls;
+  struct ExtLayout { int32_t ngl = 0; std::vector<int64_t> blk_off; ivec blk_len; int64_t size = 0; };
+  ExtLayout ext_layout(const Subdomain& S) const;
+  void localize();
   void build_classes();
   void build_schur_setup();
+  void exchange_records();
+  void assemble_reduced(Csr& R, ivec& row_gids, dvec* tvn);
   void schur_apply(double* rhs2, double* x2);
+  void next_apply(const double* rhs, double* sol);
+  void build_handoff(const ivec& next_owned);
   void interior_solve(double* x1);
 
   Params p_;
   int level_;
+  int64_t ngid_;
+  const Comm* comm_;
   Csr K_;
+  int32_t nrows_ = 0;        // local nodes with a row
+  ivec keep_entries_;        // sharded: entries of the rows as given that were kept (set_values)
+  size_t given_nnz_ = 0;
   ivec gids_;
   dvec tv_;
-  int64_t ngid_;
   HierMap hm_;
-  int32_t n1_ = 0, n2_ = 0;
-  ivec g2l_;                 // gid -> level row (-1)
-  ivec sep_row_;             // separator index -> level row
-  ivec pos2_;                // level row -> separator index (-1)
-  ivec intidx_;              // level row -> internal interior index (-1)
-  ivec in_perm_;             // internal index -> level row
+  bool partitioned_ = false;
+  ivec sd_rank_;             // per subdomain: owning rank
+  ivec my_sds_, halo_sds_;   // ascending
+  int64_t global_n_ = 0, global_n2_ = 0;
+  int32_t n1_ = 0, n2_ = 0, ngs_ = 0, ngi_ = 0;   // interiors, owned separators, ghost separators, ghost interiors
+  ivec g2l_;                 // gid -> local node (-1)
+  ivec sep_row_;             // separator index (owned, then ghost) -> local node
+  ivec pos2_;                // local node -> separator index (-1)
+  ivec intidx_;              // local node -> internal interior index (-1)
+  ivec in_perm_;             // internal index (interiors, owned separators) -> position in the user vector
+  ivec owned_gids_;
   ivec sd_xoff_, sd_cls_, sd_bidx_;
   ivec sep_sd_ptr_, sep_sd_;   // per separator index: the subdomains whose groups contain it
   ivec sd_center_;             // 3 ints per subdomain (mean coordinate of its separator nodes)
   std::vector<std::unique_ptr<Cls>> cls_;
+  // halo exchanges of the apply (empty on one rank)
+  Exchange xch_int_, xch_sep_, xch_down_;
+  // records of neighbouring ranks' subdomains that touch separators owned here
+  struct RecSeg { int64_t off, len; };
+  std::vector<RecSeg> rec_send_;              // in send order (peer-major)
+  std::vector<int64_t> rec_scnt_, rec_rcnt_;
+  int64_t rec_nsend_ = 0, rec_nrecv_ = 0, ext_recv_base_ = 0;
+  bool rec_any_ = false;
   // fused interior solve tables
   dev::FusedSub* d_fsubs_ = nullptr;
   dev::PlanD* d_fplans_ = nullptr;
@@ -142,16 +183,25 @@ class LevelSolver : public Operator {
   struct BlockClass { int32_t nb = 0, nblk = 0; ivec ids; ivec owner_key; double* d_binv = nullptr; int32_t* d_ids = nullptr;
                       std::vector<int64_t> pull_ptr, pull_base; int64_t* d_pull_ptr = nullptr; int64_t* d_pull_base = nullptr; };
   std::vector<BlockClass> blocks_;
-  // reduced (V-sum) matrix or full Schur complement: pattern + pull lists
-  Csr red_;                  // pattern (host), values filled after compute
+  // rows of the reduced (V-sum) matrix or of the full Schur complement owned here: pattern + pull lists
+  Csr red_;                  // col = gid of the column node
   std::vector<int64_t> red_pull_ptr_, red_pull_idx_;
   int64_t *d_red_pull_ptr_ = nullptr, *d_red_pull_idx_ = nullptr;
   double* d_red_val_ = nullptr;
   double* d_ext_ = nullptr; int64_t ext_total_ = 0;
   double *d_vrhs_ = nullptr, *d_vsol_ = nullptr, *d_yb_ = nullptr;
+  double *d_nrhs_ = nullptr, *d_nsol_ = nullptr;   // next level's right-hand side / solution in its own layout
   int32_t* d_flag_ = nullptr;
+  // the reduced matrix of all ranks (rows in rank order), rebuilt every Compute from the gathered values
+  Csr glob_;
+  ivec glob_gids_;
+  dvec glob_tv_;
+  std::vector<int64_t> glob_perm_;      // gathered entry -> entry of glob_
+  std::vector<int64_t> glob_row_off_;   // first global row of every rank
+  bool glob_ready_ = false;
   std::unique_ptr<Operator> next_;
   LevelSolver* next_level_ = nullptr;
+  bool next_is_direct_ = false;
   ivec next_pattern_key_rowptr_, next_pattern_key_col_;
   bool initialized_ = false;
 };

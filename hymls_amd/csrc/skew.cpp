@@ -204,6 +204,8 @@ int skew_num_subdomains(const Params& p) {
   return std::max(n, 1);
 }
 
+void skew_sd_position(const Params& p, int sd, int& x, int& y, int& z) { skew_position(p, sd, x, y, z); }
+
 void skew_get_groups(const Params& p, int sd, ivec& interior, std::vector<Group>& out) {
   interior.clear();
   out.clear();

@@ -1,0 +1,106 @@
+"""Transport of the sharded path: the two callbacks of include/hymls_mi.h's hymls_mi_comm on top of
+torch.distributed (backend "nccl" = RCCL over xGMI for device buffers; "gloo" for the host-side setup
+exchanges and for the CPU tests).  One process per GPU.
+
+The library decides what goes where (halo of the interior layer and of the separators around every
+SpMV, Schur records at setup, V-sum hand-off per level); this file only moves bytes:
+  alloc(bytes)          -> a torch tensor the transport can address (exchange arenas)
+  alltoallv(send, ...)  -> dist.all_to_all_single on views of those tensors, ordered on the handle's stream
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .api import A2A_FN, ALLOC_FN, _Comm
+
+
+def rank_grid(world):
+    """boxes of the grid per direction for `world` ranks: 2 -> (2,1,1), 4 -> (2,2,1), 8 -> (2,2,2) ...
+    (repeated halving x, y, z like the reference's CreatePIDMap, src/HYMLS_BasePartitioner.cpp:361-586)"""
+    g = [1, 1, 1]
+    d = 0
+    w = world
+    while w > 1:
+        assert w % 2 == 0, "number of ranks must be a power of two"
+        g[d % 3] *= 2
+        w //= 2
+        d += 1
+    return tuple(g)
+
+
+class TorchComm:
+    """device: torch.device of this rank's buffers ('cpu' with the test-only host simulator).
+    device_group: process group for device buffers (default group); host_group: gloo group for
+    host buffers (created here when the default backend cannot move host memory)."""
+
+    def __init__(self, device, device_group=None, host_group=None):
+        assert dist.is_initialized()
+        self.device = torch.device(device)
+        self.rank = dist.get_rank()
+        self.size = dist.get_world_size()
+        self.device_group = device_group
+        backend = dist.get_backend(device_group)
+        if host_group is None and backend != "gloo":
+            host_group = dist.new_group(backend="gloo")   # collective: every rank constructs its TorchComm
+        self.host_group = host_group if backend != "gloo" else (host_group or device_group)
+        self._arenas = []          # (ptr, nbytes, tensor)
+        self._stream = None
+        self._a2a = A2A_FN(self._alltoallv)
+        self._alloc = ALLOC_FN(self._alloc_arena)
+        self.c_struct = _Comm(None, self.rank, self.size, self._a2a, self._alloc)
+        self.error = None
+
+    def attach(self, prec):
+        self._prec = prec
+
+    # ---- callbacks (no exception may cross the C boundary)
+    def _alloc_arena(self, ctx, nbytes):
+        try:
+            t = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
+            self._arenas.append((t.data_ptr(), t.numel() * 8, t))
+            return t.data_ptr()
+        except Exception as e:  # pragma: no cover
+            self.error = e
+            return None
+
+    def _view(self, ptr, nbytes):
+        for base, size, t in self._arenas:
+            if base <= ptr and ptr + nbytes <= base + size:
+                off = (ptr - base) // 8
+                return t[off:off + nbytes // 8]
+        raise RuntimeError("exchange buffer outside the arenas")
+
+    def _alltoallv(self, ctx, send, scnt, recv, rcnt, elem_bytes, on_device):
+        try:
+            sc = [int(scnt[i]) for i in range(self.size)]
+            rc = [int(rcnt[i]) for i in range(self.size)]
+            if on_device:
+                assert elem_bytes == 8
+                inp = self._view(send or 0, sum(sc) * 8) if sum(sc) else torch.empty(0, dtype=torch.float64, device=self.device)
+                out = self._view(recv or 0, sum(rc) * 8) if sum(rc) else torch.empty(0, dtype=torch.float64, device=self.device)
+                if self.device.type == "cuda" and dist.get_backend(self.device_group) == "gloo":
+                    # several ranks sharing one GPU (tests): RCCL cannot do that, stage through the host
+                    torch.cuda.synchronize()
+                    ci, co = inp.cpu(), torch.empty(out.numel(), dtype=torch.float64)
+                    dist.all_to_all_single(co, ci, rc, sc, group=self.device_group)
+                    out.copy_(co)
+                    torch.cuda.synchronize()
+                elif self.device.type == "cuda":
+                    if self._stream is None:
+                        self._stream = torch.cuda.ExternalStream(self._prec.stream(), device=self.device)
+                    with torch.cuda.stream(self._stream):
+                        dist.all_to_all_single(out, inp, rc, sc, group=self.device_group)
+                else:
+                    dist.all_to_all_single(out, inp, rc, sc, group=self.device_group)
+            else:
+                nb_s, nb_r = sum(sc) * elem_bytes, sum(rc) * elem_bytes
+                inp = torch.frombuffer((C.c_char * max(nb_s, 1)).from_address(send), dtype=torch.uint8)[:nb_s]
+                out = torch.frombuffer((C.c_char * max(nb_r, 1)).from_address(recv), dtype=torch.uint8)[:nb_r]
+                dist.all_to_all_single(out, inp, [c * elem_bytes for c in rc], [c * elem_bytes for c in sc],
+                                       group=self.host_group)
+            return 0
+        except Exception as e:
+            self.error = e
+            return -1

@@ -66,6 +66,39 @@ int hymls_mi_create(hymls_mi_t** h, const hymls_mi_params* p, int device);
 int hymls_mi_set_matrix_csr(hymls_mi_t* h, int64_t nrows, const int32_t* rowptr,
                             const int32_t* colind, const double* val);
 
+/* ---- sharded runs: one process per GPU, every rank holds a handle ------------------------------
+ * The transport replaces Epetra_Comm / Epetra_Import / Epetra_Export (the importer of the
+ * overlapping matrix and vectors, reference src/HYMLS_Preconditioner.cpp:304-330; the Schur
+ * complement export, src/HYMLS_SchurComplement.cpp:195-260; the V-sum importer of the next level,
+ * src/HYMLS_SchurPreconditioner.cpp:520-629).  The library packs/unpacks and decides what goes
+ * where; the host application moves the bytes (hymls_amd/dist.py: torch.distributed, i.e. RCCL
+ * over xGMI for device buffers). */
+typedef struct hymls_mi_comm {
+  void* ctx;
+  int32_t rank, size;
+  /* all-to-all of contiguous per-peer segments (counts in elements of elem_bytes, `size` entries each).
+   * on_device != 0: both pointers lie inside arenas obtained from alloc() and the operation must be
+   * ordered on hymls_mi_stream(); otherwise host memory.  Returns 0 on success. */
+  int (*alltoallv)(void* ctx, const void* send, const int64_t* sendcounts, void* recv,
+                   const int64_t* recvcounts, int32_t elem_bytes, int32_t on_device);
+  /* device memory the transport can address (kept alive by the application for the handle's lifetime) */
+  void* (*alloc)(void* ctx, int64_t bytes);
+} hymls_mi_comm;
+
+/* rank r owns the box (r % px, (r / px) % py, r / (px*py)) of the grid, as the reference's
+ * CreatePIDMap (src/HYMLS_BasePartitioner.cpp:361-586); call before any matrix is set.  Collective. */
+int hymls_mi_set_comm(hymls_mi_t* h, const hymls_mi_comm* comm, int px, int py, int pz);
+/* the rows this rank has to be given: interiors and separators of its subdomains (the overlapping
+ * row map of the reference).  Two-call protocol (gids == NULL: count only); ascending gids. */
+int hymls_mi_required_rows(hymls_mi_t* h, int64_t* n, int32_t* gids);
+/* this rank's rows (at least the required ones), CSR with GLOBAL column ids; replaces
+ * hymls_mi_set_matrix_csr on a sharded handle.  hymls_mi_set_testvector then takes one value per row given. */
+int hymls_mi_set_matrix_rows(hymls_mi_t* h, int64_t nrows, const int32_t* gids, const int32_t* rowptr,
+                             const int32_t* colgid, const double* val);
+/* after Initialize: the rows whose entries this rank's B and X hold in ApplyInverse (interiors of its
+ * subdomains and the separators it owns), in the order the rows were given. */
+int hymls_mi_owned_rows(const hymls_mi_t* h, int64_t* n, int32_t* gids);
+
 /* optional test vector (ctor argument testVector; default all ones,
  * src/HYMLS_Preconditioner.cpp:781-787). Host pointer, n entries. */
 int hymls_mi_set_testvector(hymls_mi_t* h, const double* v);
@@ -138,6 +171,9 @@ int hymls_mi_get_separator_groups(const hymls_mi_t* h, int level, int sd, int32_
 int hymls_mi_generate_matrix(int equations, int nx, int ny, int nz, double a, double b,
                              int64_t* nrows, int64_t* nnz, int32_t* rowptr, int32_t* colind,
                              double* val);
+/* the same generators for a list of rows (sharded runs); nnz returned in *nnz (rowptr == NULL: count only) */
+int hymls_mi_generate_rows(int equations, int nx, int ny, int nz, double a, double b, int64_t nrows,
+                           const int32_t* gids, int64_t* nnz, int32_t* rowptr, int32_t* colgid, double* val);
 /* create_testvector (reference src/HYMLS_MainUtils.cpp:208-258). */
 int hymls_mi_generate_testvector(int64_t nrows, const int32_t* rowptr, const int32_t* colind,
                                  const double* val, double* tv);

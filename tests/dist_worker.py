@@ -1,0 +1,80 @@
+"""Worker of the sharded-path tests (launched through torch.distributed.run, one process per rank):
+builds the sharded preconditioner, applies it to this rank's part of a seeded global vector and lets
+rank 0 compare the assembled result with the one-rank preconditioner on the same problem.
+  python -m torch.distributed.run --nproc-per-node W tests/dist_worker.py EQ NX NY NZ SX LEVELS CX PART MODE
+MODE = hostsim (TEST-ONLY CPU simulator of the device plan, gloo) | gpu (all ranks share cuda:0, gloo staging)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import hymls_amd
+from hymls_amd.dist import TorchComm, rank_grid
+
+
+def main():
+    eq, nx, ny, nz, sx, levels, cx, part, mode = sys.argv[1:10]
+    nx, ny, nz, sx, levels, cx = int(nx), int(ny), int(nz), int(sx), int(levels), int(cx)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if mode == "hostsim":
+        lib = hymls_amd.load_library(os.path.join(ROOT, "tests", "hostsim", "libhymls_mi_hostsim.so"))
+        device = "cpu"
+    else:
+        lib = hymls_amd.load_library()
+        device = "cuda:0"
+    prec = {"Separator Length": sx, "Number of Levels": levels, "Partitioner": part}
+    if cx > 0:
+        prec["Coarsening Factor"] = cx
+    prm = {"Problem": {"Equations": eq, "Dimension": 3, "nx": nx, "ny": ny, "nz": nz}, "Preconditioner": prec}
+    a = float(nx * nx)
+    comm = TorchComm(device)
+    P = hymls_amd.Preconditioner(None, prm, lib=lib, comm=comm, rank_grid=rank_grid(world))
+    req = P.RequiredRows()
+    rows = hymls_amd.generate_rows(eq, nx, ny, nz, req, a=a, lib=lib)
+    P.SetMatrixRows(req, rows)
+    P.SetTestVector(hymls_amd.generate_testvector_rows(req, *rows))
+    P.Initialize()
+    P.Compute()
+    owned = P.OwnedRows()
+    N = nx * ny * nz * (1 if eq == "Laplace" else 4)
+    b = np.random.default_rng(5).uniform(-1, 1, N)
+    x_loc = P.ApplyInverse(b[owned])
+    x_loc2 = P.ApplyInverse(b[owned])          # a second call must reproduce the first (buffers reused)
+    P.SetMatrixRows(req, rows)                 # SetMatrix with the same pattern + Compute again
+    P.Compute()
+    x_loc3 = P.ApplyInverse(b[owned])
+    parts = [None] * world
+    dist.all_gather_object(parts, (owned, x_loc, float(np.abs(x_loc2 - x_loc).max()), float(np.abs(x_loc3 - x_loc).max())))
+    ok = True
+    if rank == 0:
+        x = np.full(N, np.nan)
+        cover = np.zeros(N, np.int64)
+        for o, xl, _, _ in parts:
+            x[o] = xl
+            cover[o] += 1
+        K = hymls_amd.generate_matrix(eq, nx, ny, nz, a=a, lib=lib)
+        tv = hymls_amd.generate_testvector(*K, lib=lib)
+        P0 = hymls_amd.Preconditioner(K, prm, testVector=tv, lib=lib)
+        P0.Compute()
+        x0 = P0.ApplyInverse(b)
+        err = float(np.linalg.norm(x - x0) / np.linalg.norm(x0))
+        res = {"world": world, "cover_ok": bool((cover == 1).all()), "rel_err": err,
+               "repeat_diff": max(p[2] for p in parts), "recompute_diff": max(p[3] for p in parts),
+               "levels": P0.level_sizes(), "levels_sharded": P.level_sizes()}
+        print("DIST_RESULT " + json.dumps(res), flush=True)
+        ok = res["cover_ok"] and err < 1e-9 and res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""-m "not gpu": the sharded path on CPU: world_size 2/4/8 `gloo` ranks, each driving the
+TEST-ONLY host simulator through the C ABI with hymls_amd.dist.TorchComm as the transport.  The
+assembled result of the sharded ApplyInverse must equal the one-rank result on the same problem
+(same partition, same ownership, same summation order => agreement to rounding), which in turn is
+checked against the oracle in test_hostsim_parity.py.  The GPU version of the same check (ranks sharing
+one card) is tests/test_gpu_parity.py::test_sharded_matches_single_gpu."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    # world, eq, nx, ny, nz, sx, levels, cx, partitioner
+    (2, "Laplace", 16, 8, 8, 4, 1, -1, "Cartesian"),
+    (2, "Stokes-C", 16, 8, 8, 4, 1, -1, "Skew Cartesian"),
+    (2, "Stokes-C", 16, 8, 8, 4, 0, -1, "Skew Cartesian"),
+    (4, "Laplace", 16, 16, 8, 4, 2, 2, "Cartesian"),
+    (8, "Stokes-C", 16, 16, 16, 4, 2, 2, "Skew Cartesian"),
+]
+
+
+def run_worker(world, args, mode, port, timeout=900):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
+    cmd += [str(a) for a in args] + [mode]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("DIST_RESULT ")]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
+    return json.loads(lines[-1][len("DIST_RESULT "):])
+
+
+@pytest.mark.parametrize("world,eq,nx,ny,nz,sx,levels,cx,part", CASES)
+def test_sharded_matches_one_rank(hostsim_lib, world, eq, nx, ny, nz, sx, levels, cx, part):
+    res = run_worker(world, (eq, nx, ny, nz, sx, levels, cx, part), "hostsim", 29520 + world)
+    assert res["cover_ok"]                       # every row owned by exactly one rank
+    assert res["levels"] == res["levels_sharded"]
+    assert res["rel_err"] < 1e-12
+    assert res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12

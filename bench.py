@@ -8,8 +8,13 @@ BASELINE.json configs[1]: Stokes3D 128^3 (8 388 608 DoF), 2-level (XML "Number o
 separator length 8.  The 3D Stokes-C problem is partitioned with the reference's "Skew
 Cartesian" partitioner, the only one the reference itself can run 3D Stokes with.
 
-N > 1 (launched through torch.distributed.run): every rank runs the same workload on its own
-GPU (replicas, no exchange step yet -- DESIGN.md section "multi-GPU"); value is the aggregate.
+N > 1 (launched through torch.distributed.run, one rank per GPU): the path is sharded (DESIGN.md
+section "multi-GPU"): rank r owns one 128^3 box of a (128 px) x (128 py) x (128 pz) grid (2 -> 2x1x1,
+4 -> 2x2x1, 8 -> 2x2x2 = the 256^3 problem of BASELINE.json configs[2]), its subdomains, and the
+separators they list first; halo values and the V-sum hand-off travel through torch.distributed
+(RCCL).  Weak scaling: the work per GPU is fixed, value = global DoF / time.  N > 1 uses one more
+level (XML "Number of Levels" = 2, the 3-level method configs[2] names) because the V-sum system of
+256^3 is too large for a direct solve.  `--replicas` runs N independent copies of the N = 1 workload instead.
 """
 import argparse
 import json
@@ -65,7 +70,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", dest="n", type=int, default=128, help="grid size per direction")
     ap.add_argument("--sx", type=int, default=8)
-    ap.add_argument("--levels", type=int, default=1)
+    ap.add_argument("--levels", type=int, default=None, help="XML 'Number of Levels' (default 1; 2 for the sharded N > 1 run)")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies instead of the sharded problem")
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -96,15 +102,47 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    n, sx, levels = args.n, args.sx, args.levels
-    rp, ci, va = hymls_amd.generate_matrix("Stokes-C", n, n, n, lib=lib)
-    tv = hymls_amd.generate_testvector(rp, ci, va, lib=lib)
-    prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": n, "ny": n, "nz": n},
-           "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
-    P = hymls_amd.Preconditioner((rp, ci, va), prm, testVector=tv, device=local_rank, lib=lib)
-    t0 = time.time(); P.Initialize(); t_init = time.time() - t0
-    t0 = time.time(); P.Compute(); t_comp = time.time() - t0
-    N = rp.size - 1
+    n, sx = args.n, args.sx
+    sharded = world > 1 and not args.replicas
+    note = None
+    if sharded:
+        # self-test of the transport on this backend (uneven all-to-all on the library's stream); if any rank
+        # fails, every rank falls back to replicas and the line says so
+        from hymls_amd.dist import TorchComm, rank_grid, transport_selftest
+        err = transport_selftest(dev, backend)
+        if err:
+            sharded, note = False, "sharded transport self-test failed (%s): replicas" % err
+    levels = args.levels if args.levels is not None else (2 if sharded else 1)
+    if sharded:
+        px, py, pz = rank_grid(world)
+        nx, ny, nz = n * px, n * py, n * pz
+        prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": nx, "ny": ny, "nz": nz},
+               "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
+        comm = TorchComm(dev)
+        P = hymls_amd.Preconditioner(None, prm, device=local_rank, lib=lib, comm=comm, rank_grid=(px, py, pz))
+        t0 = time.time()
+        req = P.RequiredRows()
+        rows = hymls_amd.generate_rows("Stokes-C", nx, ny, nz, req, a=float(nx * nx), lib=lib)
+        P.SetMatrixRows(req, rows)
+        P.SetTestVector(hymls_amd.generate_testvector_rows(req, *rows))
+        del rows
+        P.Initialize(); t_init = time.time() - t0
+        t0 = time.time(); P.Compute(); t_comp = time.time() - t0
+        N_local = P.OwnedRows().size
+        N_global = nx * ny * nz * 4
+    else:
+        nx = ny = nz = n
+        rp, ci, va = hymls_amd.generate_matrix("Stokes-C", n, n, n, lib=lib)
+        tv = hymls_amd.generate_testvector(rp, ci, va, lib=lib)
+        prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": n, "ny": n, "nz": n},
+               "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
+        P = hymls_amd.Preconditioner((rp, ci, va), prm, testVector=tv, device=local_rank, lib=lib)
+        t0 = time.time(); P.Initialize(); t_init = time.time() - t0
+        t0 = time.time(); P.Compute(); t_comp = time.time() - t0
+        N_local = rp.size - 1
+        N_global = N_local * world
+        del rp, ci, va
+    N = N_local
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
     b = torch.rand(N, dtype=torch.float64, device=dev, generator=g) * 2 - 1
     x = torch.empty_like(b)
@@ -135,16 +173,21 @@ def main():
     t_phase = [P.last_apply_seconds(i) for i in range(5)]   # averages over the timed steps
     P.set_profiling(False)
     assert bool(np.isfinite(x).all() if args.hostsim else torch.isfinite(x).all()), "ApplyInverse produced non-finite values"
+    bytes_all = [P.apply_bytes(i) for i in range(6)]
+    bytes_rank0 = list(bytes_all)
+    if world > 1:   # algorithmic bytes of the whole job = sum over the ranks
+        t = torch.tensor(bytes_all, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        bytes_all = [float(v) for v in t.tolist()]
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
-        bytes_all = [P.apply_bytes(i) for i in range(6)]
         # dominant kernel: k_interior_fused (two launches per ApplyInverse).  Algorithmic bytes
         # per launch = every stored factor-panel entry once (8 B, forward reads L-side, backward
         # U-side) + the interior vector in and out.
         lv = P.level_sizes()
-        n1 = lv[0][1] - lv[0][2]
-        bytes_launch = bytes_all[1] / 2.0 + 16.0 * n1
+        n1 = (lv[0][1] - lv[0][2]) / (world if sharded else 1)   # interior unknowns per GPU
+        bytes_launch = bytes_rank0[1] / 2.0 + 16.0 * n1          # this rank's launch
         t_launch = t_phase[1] / 2.0
         achieved = bytes_launch / t_launch / 1e9 if t_launch > 0 else None
         # HBM traffic of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
@@ -167,13 +210,17 @@ def main():
                 traffic = None
         out = {
             "metric": "Preconditioner ApplyInverse DoF/s + achieved HBM GB/s, Stokes3D",
-            "value": N * world * args.steps / elapsed, "unit": "DoF/s",
+            "value": N_global * args.steps / elapsed, "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not args.hostsim else "synthetic (HOST SIMULATOR, TEST ONLY - not a measurement)",
-            "config": {"workload": "GaleriExt Stokes3D %d^3 (a=nx^2,b=1), %d DoF per GPU, HYMLS %d-level (Number of Levels=%d), "
-                                   "Skew Cartesian sx=%d, Block Diagonal, 1 rhs" % (n, N, levels + 1, levels, sx),
-                       "parallelism": "1 GPU" if world == 1 else "%d replicas (one problem per GPU, no exchange)" % world,
+            "config": {"workload": "GaleriExt Stokes3D %dx%dx%d (a=nx^2,b=1), %d DoF in total, %d^3 cells per GPU, HYMLS %d-level "
+                                   "(Number of Levels=%d), Skew Cartesian sx=%d, Block Diagonal, 1 rhs"
+                                   % (nx, ny, nz, N_global if sharded else N_local, n, levels + 1, levels, sx),
+                       "parallelism": "1 GPU" if world == 1 else (
+                           "sharded: %dx%dx%d boxes of %d^3 cells, one per GPU; halo + V-sum exchange over torch.distributed (%s)"
+                           % (px, py, pz, n, backend) if sharded else
+                           (note or "%d replicas (one problem per GPU, no exchange)" % world)),
                        "levels": lv, "initialize_s": t_init, "compute_s": t_comp},
             "hbm_gbps": bytes_all[0] / (elapsed / args.steps) / 1e9,
             "apply_bytes": {"total": bytes_all[0], "interior_factors": bytes_all[1], "a12_a21": bytes_all[2],

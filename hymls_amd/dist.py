@@ -30,6 +30,46 @@ def rank_grid(world):
     return tuple(g)
 
 
+def transport_selftest(device, backend):
+    """Collective: an uneven all_to_all_single of float64 device buffers on a side stream, the operation the
+    sharded ApplyInverse relies on.  Returns None if it works on every rank, else a short reason."""
+    device = torch.device(device)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    err = None
+    try:
+        sc = [(rank + q) % 3 for q in range(world)]            # what I send to q
+        rc = [(q + rank) % 3 for q in range(world)]            # what q sends to me
+        inp = torch.cat([torch.full((c,), float(rank * 100 + q), dtype=torch.float64, device=device) for q, c in enumerate(sc)]
+                        + [torch.empty(0, dtype=torch.float64, device=device)])
+        out = torch.full((sum(rc),), -1.0, dtype=torch.float64, device=device)
+        if device.type == "cuda" and backend != "gloo":
+            st = torch.cuda.Stream(device=device)
+            ext = torch.cuda.ExternalStream(st.cuda_stream, device=device)
+            with torch.cuda.stream(ext):
+                dist.all_to_all_single(out, inp, rc, sc)
+            st.synchronize()
+        elif device.type == "cuda":
+            co = torch.empty(out.numel(), dtype=torch.float64)
+            dist.all_to_all_single(co, inp.cpu(), rc, sc)
+            out.copy_(co)
+        else:
+            dist.all_to_all_single(out, inp, rc, sc)
+        exp = torch.cat([torch.full((c,), float(q * 100 + rank), dtype=torch.float64) for q, c in enumerate(rc)]
+                        + [torch.empty(0, dtype=torch.float64)])
+        if not torch.equal(out.cpu(), exp):
+            err = "wrong data"
+    except Exception as e:  # pragma: no cover
+        err = type(e).__name__ + ": " + str(e)[:120]
+    flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=device if backend != "gloo" else "cpu")
+    try:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    except Exception as e:  # pragma: no cover
+        return err or (type(e).__name__ + ": " + str(e)[:120])
+    if flag.item() > 0:
+        return err or "failed on another rank"
+    return None
+
+
 class TorchComm:
     """device: torch.device of this rank's buffers ('cpu' with the test-only host simulator).
     device_group: process group for device buffers (default group); host_group: gloo group for

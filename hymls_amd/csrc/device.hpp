@@ -133,6 +133,22 @@ struct FusedSub {
 constexpr int FUSED_MAX_ITEMS = 2048;  // max work items (rows) of one tree level handled by the fused kernel
 void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, double* x);
 
+// ---- merged level-synchronous solve of the classes that do not fit the fused kernel (large subdomains
+// of the coarser levels): ONE launch per tree level and sweep covers every (class, member, front) of that
+// level.  A task is one workgroup: a whole small front, or a 64-row tile of a large one (all its columns;
+// the assembly of the pivot entries it needs is fused in, which is why the forward sweep reads x and
+// writes y instead of working in place).
+struct LvlSub { const double* fac; double* contrib; int32_t xoff, cls; };   // one (class, member)
+struct LvlTask { int32_t sub, front, r0, pad; };   // r0 < 0: whole front; else rows [r0, r0 + 64)
+constexpr int LVL_MAX_ROWS = 6144;                 // w + ri limit of a front on this path (LDS vector)
+constexpr int LVL_SMALL_ROWS = 256;                // fronts up to this many rows are one task
+// y[pivots] = forward-substituted values, contributions pushed to the parents' assembly
+void solve_fwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
+                     const double* x, double* y);
+// x[pivots] = U^{-1} y - (U^{-1} U12) x[ancestors]
+void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
+                     const double* y, double* x);
+
 // ---- separator-side kernels
 // Householder per owned group on a level separator vector: x <- 2 w (w.x) - x
 // gptr[ng+1] offsets into the separator vector; w = 0 rows mean "x <- -x" (reference quirk)

@@ -1036,6 +1036,179 @@ void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32
   }
 }
 
+// ------------------------------------------------------------------ merged level solve
+// (see device.hpp) one workgroup per task, 256 threads.  Tile tasks: lane = row (coalesced 512-byte panel
+// loads), the four waves split the columns, fixed-order reduction through LDS (bitwise reproducible).
+__global__ void __launch_bounds__(256) k_lvl_fwd(const LvlTask* __restrict__ tasks, const LvlSub* __restrict__ subs,
+                                                  const PlanD* __restrict__ plans, const double* __restrict__ x,
+                                                  double* __restrict__ y) {
+  extern __shared__ double f[];
+  const LvlTask T = tasks[blockIdx.x];
+  const LvlSub S = subs[T.sub];
+  const PlanD* P = plans + S.cls;
+  const FrontD F = P->fronts[T.front];
+  const int tid = threadIdx.x, w = F.w, rows = F.w + F.ri;
+  const int64_t ld = rows;
+  const double* xb = x + S.xoff;
+  double* yb = y + S.xoff;
+  double* cb = S.contrib;
+  const int32_t* __restrict__ aptr = P->asm_ptr + F.a_off;
+  const int32_t* __restrict__ asrc = P->asm_src;
+  const double* __restrict__ Lp = S.fac + F.lp_off;
+  if (T.r0 < 0) {
+    for (int j = tid; j < rows; j += 256) {
+      double v = j < w ? xb[F.c0 + j] : 0.0;
+      for (int t = aptr[j]; t < aptr[j + 1]; t++) v += cb[asrc[t]];
+      f[j] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < rows; i += 256) {
+      const int kmax = i < w ? i : w;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = 0;
+      for (; k + 3 < kmax; k += 4) {
+        s0 += Lp[i + ld * k] * f[k];
+        s1 += Lp[i + ld * (k + 1)] * f[k + 1];
+        s2 += Lp[i + ld * (k + 2)] * f[k + 2];
+        s3 += Lp[i + ld * (k + 3)] * f[k + 3];
+      }
+      for (; k < kmax; k++) s0 += Lp[i + ld * k] * f[k];
+      const double s = (s0 + s1) + (s2 + s3);
+      if (i < w) yb[F.c0 + i] = f[i] + s;
+      else cb[F.c_off + i - w] = f[i] - s;
+    }
+    return;
+  }
+  const int r0 = T.r0, lane = tid & 63, g = tid >> 6, i = r0 + lane;
+  const int kneed = min(w, r0 + 63);                 // row i uses columns k < min(i, w)
+  double* own = f + ((kneed + 7) & ~7);
+  double (*red)[64] = (double (*)[64])(own + 64);
+  for (int j = tid; j < kneed; j += 256) {
+    double v = xb[F.c0 + j];
+    for (int t = aptr[j]; t < aptr[j + 1]; t++) v += cb[asrc[t]];
+    f[j] = v;
+  }
+  if (tid < 64 && i < rows) {
+    double v = i < w ? xb[F.c0 + i] : 0.0;
+    for (int t = aptr[i]; t < aptr[i + 1]; t++) v += cb[asrc[t]];
+    own[lane] = v;
+  }
+  __syncthreads();
+  const int krow = i < rows ? (i < w ? i : w) : 0;
+  const double* __restrict__ Lr = Lp + (i < rows ? i : 0);
+  const int chunk = ((kneed + 31) / 32) * 8;
+  const int kb = g * chunk, ke = min(kb + chunk, kneed);
+  double acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) acc[u] = 0.0;
+  int k = kb;
+  for (; k + 7 < ke; k += 8) {
+    double l[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) l[u] = Lr[ld * (k + u)];
+#pragma unroll
+    for (int u = 0; u < 8; u++) if (k + u < krow) acc[u] += l[u] * f[k + u];
+  }
+  for (; k < ke; k++) if (k < krow) acc[0] += Lr[ld * k] * f[k];
+  red[g][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (g == 0 && i < rows) {
+    const double sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (i < w) yb[F.c0 + i] = own[lane] + sum;
+    else cb[F.c_off + i - w] = own[lane] - sum;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_lvl_bwd(const LvlTask* __restrict__ tasks, const LvlSub* __restrict__ subs,
+                                                  const PlanD* __restrict__ plans, const double* __restrict__ y,
+                                                  double* __restrict__ x) {
+  extern __shared__ double f[];
+  const LvlTask T = tasks[blockIdx.x];
+  const LvlSub S = subs[T.sub];
+  const PlanD* P = plans + S.cls;
+  const FrontD F = P->fronts[T.front];
+  const int tid = threadIdx.x, w = F.w, ri = F.ri;
+  const int64_t ld = w + ri;
+  double* xb = x + S.xoff;
+  const double* yb = y + S.xoff;
+  const int32_t* __restrict__ idx = P->fidx + F.idx_off + w;
+  const double* __restrict__ Lp = S.fac + F.lp_off;
+  const double* __restrict__ Q = S.fac + F.q_off;
+  if (T.r0 < 0) {
+    for (int k = tid; k < w + ri; k += 256) f[k] = k < w ? yb[F.c0 + k] : xb[idx[k - w]];
+    __syncthreads();
+    for (int i = tid; i < w; i += 256) {
+      double s = 0.0;
+      for (int k = i; k < w; k++) s += Lp[i + ld * k] * f[k];
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = 0;
+      for (; k + 3 < ri; k += 4) {
+        s0 += Q[i + (int64_t)w * k] * f[w + k];
+        s1 += Q[i + (int64_t)w * (k + 1)] * f[w + k + 1];
+        s2 += Q[i + (int64_t)w * (k + 2)] * f[w + k + 2];
+        s3 += Q[i + (int64_t)w * (k + 3)] * f[w + k + 3];
+      }
+      for (; k < ri; k++) s0 += Q[i + (int64_t)w * k] * f[w + k];
+      xb[F.c0 + i] = s - ((s0 + s1) + (s2 + s3));
+    }
+    return;
+  }
+  const int r0 = T.r0, lane = tid & 63, g = tid >> 6, i = r0 + lane;
+  const int nU = w - r0, total = nU + ri;            // columns r0..w-1 of the pivot block, then the U-side panel
+  double (*red)[64] = (double (*)[64])(f + ((total + 7) & ~7));
+  for (int k = tid; k < total; k += 256) f[k] = k < nU ? yb[F.c0 + r0 + k] : xb[idx[k - nU]];
+  __syncthreads();
+  const int iv = i < w ? i : r0;
+  const double* __restrict__ Lr = Lp + iv + ld * r0;   // column r0 + kk
+  const double* __restrict__ Qr = Q + iv;
+  const int chunk = ((total + 31) / 32) * 8;
+  const int kb = g * chunk, ke = min(kb + chunk, total);
+  double acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) acc[u] = 0.0;
+  // pivot-block part of this wave's range
+  {
+    const int e = min(ke, nU);
+    int k = kb;
+    for (; k + 7 < e; k += 8) {
+      double l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) l[u] = Lr[ld * (k + u)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (k + u >= lane) acc[u] += l[u] * f[k + u];
+    }
+    for (; k < e; k++) if (k >= lane) acc[0] += Lr[ld * k] * f[k];
+  }
+  // U-side panel part
+  {
+    int k = max(kb, nU);
+    for (; k + 7 < ke; k += 8) {
+      double l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) l[u] = Qr[(int64_t)w * (k - nU + u)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] -= l[u] * f[k + u];
+    }
+    for (; k < ke; k++) acc[0] -= Qr[(int64_t)w * (k - nU)] * f[k];
+  }
+  red[g][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (g == 0 && i < w) xb[F.c0 + i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+void solve_fwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
+                     const double* x, double* y) {
+  if (ntasks <= 0) return;
+  hipLaunchKernelGGL(k_lvl_fwd, dim3(ntasks), dim3(256), (size_t)lds_doubles * sizeof(double), g_stream, tasks, subs, plans, x, y);
+  launch_check();
+}
+void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
+                     const double* y, double* x) {
+  if (ntasks <= 0) return;
+  hipLaunchKernelGGL(k_lvl_bwd, dim3(ntasks), dim3(256), (size_t)lds_doubles * sizeof(double), g_stream, tasks, subs, plans, y, x);
+  launch_check();
+}
+
 // ------------------------------------------------------------------ fused interior solve
 // One workgroup per subdomain, level-synchronous: all fronts of one tree level are processed
 // together, one work item per row of [pivot | update rows] (forward) or per pivot row (backward),

@@ -304,6 +304,7 @@ LevelSolver::~LevelSolver() {
                   d_nrhs_, d_nsol_};
   for (void* q : ptrs) dev::free(q);
   dev::free(d_fsubs_); dev::free(d_fplans_);
+  dev::free(d_lsubs_); dev::free(d_lfw_); dev::free(d_lbw_); dev::free(d_ytmp_);
   for (auto& b : blocks_) { dev::free(b.d_binv); dev::free(b.d_ids); dev::free(b.d_pull_ptr); dev::free(b.d_pull_base); }
 }
 
@@ -911,7 +912,7 @@ void LevelSolver::build_schur_setup() {
     bool any_big = false;
     for (auto& L : C.lu.plan.big_levels) any_big |= !L.empty();
     if (any_big || C.lu.plan.max_level_rows > dev::FUSED_MAX_ITEMS || need > LDS_CAP || C.lu.plan.nI == 0 ||
-        C.lu.plan.fw_items.empty()) continue;
+        C.lu.plan.fw_items.empty() || std::getenv("HYMLS_MI_NO_FUSED_SOLVE")) continue;
     cls_fused_[c] = 1;
     fused_lds_ = std::max(fused_lds_, need);
     for (size_t b = 0; b < C.lu.members.size(); b++)
@@ -923,6 +924,71 @@ void LevelSolver::build_schur_setup() {
                  comm_->rank, level_, n_fsubs_, my_sds_.size(), fused_lds_, fused_lds_ * 8.0 / 1024);
   d_fplans_ = dev::upload(plans);
   d_fsubs_ = dev::upload(subs);
+  // ---- merged level solve for the classes that do not fit (large subdomains of the coarser levels):
+  // one launch per tree level and sweep for all of them together
+  cls_merged_.assign(cls_.size(), 0);
+  const int small_rows = std::getenv("HYMLS_MI_LVL_SMALL_ROWS") ? std::atoi(std::getenv("HYMLS_MI_LVL_SMALL_ROWS")) : dev::LVL_SMALL_ROWS;
+  std::vector<dev::LvlSub> lsubs;
+  std::vector<std::vector<std::pair<int64_t, dev::LvlTask>>> fw, bw;   // per tree level: (cost, task)
+  for (size_t c = 0; c < cls_.size(); c++) {
+    Cls& C = *cls_[c];
+    if (cls_fused_[c] || C.lu.plan.nI == 0 || std::getenv("HYMLS_MI_NO_MERGED_SOLVE")) continue;
+    bool ok = true;
+    for (auto& F : C.lu.plan.fronts) ok &= F.w + F.ri <= dev::LVL_MAX_ROWS;
+    if (!ok) continue;
+    cls_merged_[c] = 1;
+    const size_t nl = C.lu.plan.levels.size();
+    if (fw.size() < nl) { fw.resize(nl); bw.resize(nl); }
+    for (size_t b = 0; b < C.lu.members.size(); b++) {
+      const int32_t sub = (int32_t)lsubs.size();
+      lsubs.push_back(dev::LvlSub{C.lu.batch.factor + (int64_t)b * C.lu.plan.factor_size,
+                                  C.lu.batch.contrib + (int64_t)b * C.lu.plan.contrib_size, C.lu.h_xoff[b], (int32_t)c});
+      for (size_t l = 0; l < nl; l++) {
+        auto add = [&](int s) {
+          const Front& F = C.lu.plan.fronts[s];
+          const int rows = F.w + F.ri;
+          if (rows <= small_rows) {
+            fw[l].push_back({(int64_t)rows * F.w, dev::LvlTask{sub, s, -1, 0}});
+            bw[l].push_back({(int64_t)rows * F.w, dev::LvlTask{sub, s, -1, 0}});
+          } else {
+            for (int r0 = 0; r0 < rows; r0 += 64) fw[l].push_back({64LL * std::min(F.w, r0 + 63), dev::LvlTask{sub, s, r0, 0}});
+            for (int r0 = 0; r0 < F.w; r0 += 64) bw[l].push_back({64LL * (F.w - r0 + F.ri), dev::LvlTask{sub, s, r0, 0}});
+          }
+        };
+        for (int s : C.lu.plan.levels[l]) add(s);
+        for (int s : C.lu.plan.big_levels[l]) add(s);
+      }
+    }
+  }
+  n_lsubs_ = (int32_t)lsubs.size();
+  lvl_fw_off_.assign(1, 0); lvl_bw_off_.assign(1, 0); lvl_fw_lds_.clear(); lvl_bw_lds_.clear();
+  if (n_lsubs_) {
+    std::vector<dev::LvlTask> tf, tb;
+    auto heavy_first = [](const std::pair<int64_t, dev::LvlTask>& a, const std::pair<int64_t, dev::LvlTask>& b) { return a.first > b.first; };
+    for (size_t l = 0; l < fw.size(); l++) {
+      std::stable_sort(fw[l].begin(), fw[l].end(), heavy_first);
+      std::stable_sort(bw[l].begin(), bw[l].end(), heavy_first);
+      int32_t lf = 0, lb = 0;
+      for (auto& t : fw[l]) {
+        const Front& F = cls_[lsubs[t.second.sub].cls]->lu.plan.fronts[t.second.front];
+        lf = std::max(lf, t.second.r0 < 0 ? F.w + F.ri : ((std::min(F.w, t.second.r0 + 63) + 7) & ~7) + 64 + 256);
+        tf.push_back(t.second);
+      }
+      for (auto& t : bw[l]) {
+        const Front& F = cls_[lsubs[t.second.sub].cls]->lu.plan.fronts[t.second.front];
+        lb = std::max(lb, t.second.r0 < 0 ? F.w + F.ri : ((F.w - t.second.r0 + F.ri + 7) & ~7) + 256);
+        tb.push_back(t.second);
+      }
+      lvl_fw_off_.push_back((int32_t)tf.size()); lvl_bw_off_.push_back((int32_t)tb.size());
+      lvl_fw_lds_.push_back(lf); lvl_bw_lds_.push_back(lb);
+    }
+    d_lsubs_ = dev::upload(lsubs);
+    d_lfw_ = dev::upload(tf); d_lbw_ = dev::upload(tb);
+    d_ytmp_ = (double*)dev::alloc((size_t)std::max(n1_, 1) * sizeof(double));
+    if (std::getenv("HYMLS_MI_VERBOSE"))
+      std::fprintf(stderr, "[hymls_mi] rank %d level %d: merged level solve for %d subdomains, %zu tree levels, %zu + %zu tasks\n",
+                   comm_->rank, level_, n_lsubs_, fw.size(), tf.size(), tb.size());
+  }
 }
 
 // the extraction records of boundary subdomains travel to the ranks that own some of their separators
@@ -1121,8 +1187,15 @@ void LevelSolver::compute() {
 
 void LevelSolver::interior_solve(double* x1) {
   if (n_fsubs_ > 0) dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, x1);
+  if (n_lsubs_ > 0) {
+    const int nl = (int)lvl_fw_lds_.size();
+    for (int l = 0; l < nl; l++)
+      dev::solve_fwd_tasks(d_lfw_ + lvl_fw_off_[l], lvl_fw_off_[l + 1] - lvl_fw_off_[l], d_lsubs_, d_fplans_, lvl_fw_lds_[l], x1, d_ytmp_);
+    for (int l = nl - 1; l >= 0; l--)
+      dev::solve_bwd_tasks(d_lbw_ + lvl_bw_off_[l], lvl_bw_off_[l + 1] - lvl_bw_off_[l], d_lsubs_, d_fplans_, lvl_bw_lds_[l], d_ytmp_, x1);
+  }
   for (size_t c = 0; c < cls_.size(); c++)
-    if (!cls_fused_[c]) cls_[c]->lu.solve(x1);
+    if (!cls_fused_[c] && !cls_merged_[c]) cls_[c]->lu.solve(x1);
 }
 
 // rhs/sol: entries of the nodes this rank owns on this level that go on to the next one

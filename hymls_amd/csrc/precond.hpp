@@ -164,6 +164,13 @@ class LevelSolver : public Operator {
   dev::PlanD* d_fplans_ = nullptr;
   int32_t n_fsubs_ = 0, fused_lds_ = 0;
   std::vector<char> cls_fused_;
+  // merged level solve tables (classes too large for the fused kernel)
+  std::vector<char> cls_merged_;
+  dev::LvlSub* d_lsubs_ = nullptr;
+  dev::LvlTask *d_lfw_ = nullptr, *d_lbw_ = nullptr;
+  double* d_ytmp_ = nullptr;
+  int32_t n_lsubs_ = 0;
+  ivec lvl_fw_off_, lvl_bw_off_, lvl_fw_lds_, lvl_bw_lds_;
   // device
   double* d_kval_ = nullptr;
   int32_t *d_krow_ = nullptr, *d_kcol_ = nullptr;

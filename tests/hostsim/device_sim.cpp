@@ -202,6 +202,59 @@ void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const F
   for (int b = 0; b < B.nb; b++) for (int q = 0; q < count; q++) sim_bwd_front(P, B, P.fronts[list[q]], b, x);
 }
 
+void solve_fwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t,
+                     const double* x, double* y) {
+  // tasks of one level are independent: results first, then the writes (as the workgroups of one launch)
+  std::vector<std::pair<double*, double>> writes;
+  for (int t = 0; t < ntasks; t++) {
+    const LvlTask& T = tasks[t];
+    const LvlSub& S = subs[T.sub];
+    const PlanD& P = plans[S.cls];
+    const FrontD& F = P.fronts[T.front];
+    const int w = F.w, rows = F.w + F.ri;
+    const double* xb = x + S.xoff;
+    double* yb = y + S.xoff;
+    std::vector<double> a(rows);
+    for (int j = 0; j < rows; j++) {
+      double v = j < w ? xb[F.c0 + j] : 0.0;
+      for (int q = P.asm_ptr[F.a_off + j]; q < P.asm_ptr[F.a_off + j + 1]; q++) v += S.contrib[P.asm_src[q]];
+      a[j] = v;
+    }
+    const double* Lp = S.fac + F.lp_off;
+    const int i0 = T.r0 < 0 ? 0 : T.r0, i1 = T.r0 < 0 ? rows : std::min(rows, T.r0 + 64);
+    for (int i = i0; i < i1; i++) {
+      double s = 0;
+      for (int k = 0; k < std::min(i, w); k++) s += Lp[i + (int64_t)rows * k] * a[k];
+      if (i < w) writes.emplace_back(&yb[F.c0 + i], a[i] + s);
+      else writes.emplace_back(&S.contrib[F.c_off + i - w], a[i] - s);
+    }
+  }
+  for (auto& wv : writes) *wv.first = wv.second;
+}
+void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t,
+                     const double* y, double* x) {
+  std::vector<std::pair<double*, double>> writes;
+  for (int t = 0; t < ntasks; t++) {
+    const LvlTask& T = tasks[t];
+    const LvlSub& S = subs[T.sub];
+    const PlanD& P = plans[S.cls];
+    const FrontD& F = P.fronts[T.front];
+    const int w = F.w, ri = F.ri, ld = w + ri;
+    double* xb = x + S.xoff;
+    const double* yb = y + S.xoff;
+    const double* Lp = S.fac + F.lp_off;
+    const double* Q = S.fac + F.q_off;
+    const int i0 = T.r0 < 0 ? 0 : T.r0, i1 = T.r0 < 0 ? w : std::min(w, T.r0 + 64);
+    for (int i = i0; i < i1; i++) {
+      double s = 0;
+      for (int k = i; k < w; k++) s += Lp[i + (int64_t)ld * k] * yb[F.c0 + k];
+      for (int k = 0; k < ri; k++) s -= Q[i + (int64_t)w * k] * xb[P.fidx[F.idx_off + w + k]];
+      writes.emplace_back(&xb[F.c0 + i], s);
+    }
+  }
+  for (auto& wv : writes) *wv.first = wv.second;
+}
+
 void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t, double* x) {
   // level-synchronous walk with the same work-item tables the HIP kernel uses
   std::vector<double> C, Fv, out;

@@ -189,3 +189,17 @@ def test_sharded_matches_single_gpu(gpu_lib, world, args):
     assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
     assert res["rel_err"] < 1e-10
     assert res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("small_rows", ["256", "16"])
+def test_merged_level_solve_path_gpu(gpu_lib, monkeypatch, small_rows):
+    """k_lvl_fwd / k_lvl_bwd (solve of subdomains too large for the fused kernel), forced on a small problem:
+    whole-front tasks and 64-row tile tasks against the oracle."""
+    monkeypatch.setenv("HYMLS_MI_NO_FUSED_SOLVE", "1")
+    monkeypatch.setenv("HYMLS_MI_LVL_SMALL_ROWS", small_rows)
+    A, tv = problem("Stokes-C", 16)
+    P = product_prec(A, tv, xml_params("Stokes-C", 16, 8, 1, partitioner="Skew Cartesian"), gpu_lib)
+    O = oracle_prec(A, tv, "Stokes-C", 16, 8, 1, partitioner="Skew Cartesian")
+    b = np.random.default_rng(12).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-9

@@ -118,3 +118,16 @@ def test_lifecycle_and_errors(hostsim_lib):
     with pytest.raises(hymls_amd.HymlsError) as e:
         P.Compute()
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize("small_rows", ["256", "16"])
+def test_merged_level_solve_path(hostsim_lib, monkeypatch, small_rows):
+    """the solve path of subdomains too large for the fused kernel (one launch per tree level for all
+    classes; whole-front tasks and 64-row tile tasks), forced here on a small problem."""
+    monkeypatch.setenv("HYMLS_MI_NO_FUSED_SOLVE", "1")
+    monkeypatch.setenv("HYMLS_MI_LVL_SMALL_ROWS", small_rows)
+    A, tv = problem("Stokes-C", 16)
+    P = product_prec(A, tv, xml_params("Stokes-C", 16, 8, 1, partitioner="Skew Cartesian"), hostsim_lib)
+    O = oracle_prec(A, tv, "Stokes-C", 16, 8, 1, partitioner="Skew Cartesian")
+    b = np.random.default_rng(12).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-9

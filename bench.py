@@ -2,19 +2,18 @@
 """bench.py -- Preconditioner ApplyInverse throughput (DoF/s) + achieved HBM GB/s.
 
 Contract (see task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON
-line on rank 0.  A "step" is one ApplyInverse (one right-hand side, device-resident vectors)
-of the HYMLS preconditioner computed for the synthetic GaleriExt Stokes3D Jacobian of
-BASELINE.json configs[1]: Stokes3D 128^3 (8 388 608 DoF), 2-level (XML "Number of Levels" = 1),
-separator length 8.  The 3D Stokes-C problem is partitioned with the reference's "Skew
-Cartesian" partitioner, the only one the reference itself can run 3D Stokes with.
+line on rank 0.  A "step" is one ApplyInverse (one right-hand side, device-resident vectors) of
+the HYMLS preconditioner computed for the synthetic GaleriExt Stokes3D Jacobian the metric of
+BASELINE.json is quoted on: Stokes3D 256^3 (67 108 864 DoF), 3-level (XML "Number of Levels" = 2),
+separator length 8, coarsening factor 8 (configs[2]); it fits one MI355X (about 60 GB of factors).
+The 3D Stokes-C problem is partitioned with the reference's "Skew Cartesian" partitioner, the only
+one the reference itself can run 3D Stokes with.  `--grid 128 --levels 1` is configs[1].
 
-N > 1 (launched through torch.distributed.run, one rank per GPU): the path is sharded (DESIGN.md
-section "multi-GPU"): rank r owns one 128^3 box of a (128 px) x (128 py) x (128 pz) grid (2 -> 2x1x1,
-4 -> 2x2x1, 8 -> 2x2x2 = the 256^3 problem of BASELINE.json configs[2]), its subdomains, and the
-separators they list first; halo values and the V-sum hand-off travel through torch.distributed
-(RCCL).  Weak scaling: the work per GPU is fixed, value = global DoF / time.  N > 1 uses one more
-level (XML "Number of Levels" = 2, the 3-level method configs[2] names) because the V-sum system of
-256^3 is too large for a direct solve.  `--replicas` runs N independent copies of the N = 1 workload instead.
+N > 1 (launched through torch.distributed.run, one rank per GPU): the SAME 256^3 problem is sharded
+(strong scaling, as the metric says "256^3 Stokes3D, 1/2/4/8 GPU"): rank r owns one box of the grid
+(2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2 boxes), the subdomains in it and the separators they list first;
+halo values and the V-sum hand-off travel through torch.distributed (RCCL) -- DESIGN.md section
+"multi-GPU".  value = global DoF / time.  `--replicas` runs N independent copies instead.
 """
 import argparse
 import json
@@ -68,9 +67,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", dest="n", type=int, default=128, help="grid size per direction")
+    ap.add_argument("--grid", dest="n", type=int, default=256, help="global grid size per direction")
     ap.add_argument("--sx", type=int, default=8)
-    ap.add_argument("--levels", type=int, default=None, help="XML 'Number of Levels' (default 1; 2 for the sharded N > 1 run)")
+    ap.add_argument("--levels", type=int, default=2, help="XML 'Number of Levels' (2 = the 3-level method)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies instead of the sharded problem")
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,10 +111,10 @@ def main():
         err = transport_selftest(dev, backend)
         if err:
             sharded, note = False, "sharded transport self-test failed (%s): replicas" % err
-    levels = args.levels if args.levels is not None else (2 if sharded else 1)
+    levels = args.levels
     if sharded:
         px, py, pz = rank_grid(world)
-        nx, ny, nz = n * px, n * py, n * pz
+        nx, ny, nz = n, n, n
         prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": nx, "ny": ny, "nz": nz},
                "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
         comm = TorchComm(dev)
@@ -212,14 +211,14 @@ def main():
             "metric": "Preconditioner ApplyInverse DoF/s + achieved HBM GB/s, Stokes3D",
             "value": N_global * args.steps / elapsed, "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong" if sharded or world == 1 else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not args.hostsim else "synthetic (HOST SIMULATOR, TEST ONLY - not a measurement)",
-            "config": {"workload": "GaleriExt Stokes3D %dx%dx%d (a=nx^2,b=1), %d DoF in total, %d^3 cells per GPU, HYMLS %d-level "
+            "config": {"workload": "GaleriExt Stokes3D %dx%dx%d (a=nx^2,b=1), %d DoF, HYMLS %d-level "
                                    "(Number of Levels=%d), Skew Cartesian sx=%d, Block Diagonal, 1 rhs"
-                                   % (nx, ny, nz, N_global if sharded else N_local, n, levels + 1, levels, sx),
+                                   % (nx, ny, nz, N_global if sharded else N_local, levels + 1, levels, sx),
                        "parallelism": "1 GPU" if world == 1 else (
-                           "sharded: %dx%dx%d boxes of %d^3 cells, one per GPU; halo + V-sum exchange over torch.distributed (%s)"
-                           % (px, py, pz, n, backend) if sharded else
+                           "sharded: %dx%dx%d boxes of %dx%dx%d cells, one per GPU; halo + V-sum exchange over torch.distributed (%s)"
+                           % (px, py, pz, nx // px, ny // py, nz // pz, backend) if sharded else
                            (note or "%d replicas (one problem per GPU, no exchange)" % world)),
                        "levels": lv, "initialize_s": t_init, "compute_s": t_comp},
             "hbm_gbps": bytes_all[0] / (elapsed / args.steps) / 1e9,
@@ -232,7 +231,8 @@ def main():
                          "bytes_per_launch": bytes_launch, "launch_ms": 1e3 * t_launch, "traffic_measured_on": traffic_other},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, sx, levels)
+            # a 32^3 sample has no third level (the level-2 subdomains are 64 cells wide): 2-level sample
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, sx, min(levels, 1) if args.cpu_n < 64 else levels)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

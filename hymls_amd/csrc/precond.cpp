@@ -1,6 +1,9 @@
 // precond.cpp -- see precond.hpp
 #include "precond.hpp"
 #include <cstring>
+#include <chrono>
+#include <thread>
+#include <mutex>
 #include <map>
 #include <unordered_map>
 
@@ -22,6 +25,23 @@ inline void gid_coord(const Params& p, int32_t gid, int32_t* c) {
   const int i = cell % p.nx, j = (cell / p.nx) % p.ny, k = cell / (p.nx * p.ny);
   const int32_t vt = p.vtype[var];
   c[0] = 2 * i + (vt == VT_U); c[1] = 2 * j + (vt == VT_V); c[2] = 2 * k + (vt == VT_W);
+}
+
+// static chunks over [0, n) on up to 16 host threads (setup-time integer work only)
+template <class Fn>
+void parallel_for(int64_t n, Fn fn, int64_t grain = 256) {
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / grain}));
+  if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+  std::vector<std::thread> th;
+  std::exception_ptr err = nullptr;
+  std::mutex mu;
+  for (int t = 0; t < nt; t++)
+    th.emplace_back([&, t] {
+      try { for (int64_t i = n * t / nt; i < n * (t + 1) / nt; i++) fn(i); }
+      catch (...) { std::lock_guard<std::mutex> lk(mu); err = std::current_exception(); }
+    });
+  for (auto& x : th) x.join();
+  if (err) std::rethrow_exception(err);
 }
 
 constexpr int LEAF_SIZE = 24;
@@ -399,10 +419,21 @@ void LevelSolver::localize() {
   tv_ = std::move(tv);
 }
 
+static double wall() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 void LevelSolver::initialize() {
   const bool dist = comm_->distributed();
+  const bool verbose = std::getenv("HYMLS_MI_VERBOSE") != nullptr;
+  double t0 = wall();
+  auto lap = [&](const char* what) {
+    if (verbose) std::fprintf(stderr, "[hymls_mi] rank %d level %d: %-28s %.2f s\n", comm_->rank, level_, what, wall() - t0);
+    t0 = wall();
+  };
   if (level_ == 0) partition(nullptr);
   else { ivec lg(gids_.begin(), gids_.begin() + nrows_); partition(&lg); }
+  lap("partition");
   if (dist) localize();
   const int n = K_.n;
   HYMLS_CHECK((int)gids_.size() == n && (int)tv_.size() == n, -2, "level: inconsistent sizes");
@@ -454,7 +485,9 @@ void LevelSolver::initialize() {
   }
   ngs_ = (int32_t)sep_row_.size() - n2_;
   direct_schur_ = level_ >= p_.levels;
+  lap("separator numbering");
   build_classes();
+  lap("pattern classes + plans");
   // owned rows = layout of the vectors handed to apply_inverse (order of the rows as they were given)
   {
     ivec user(n, -1);
@@ -511,7 +544,9 @@ void LevelSolver::initialize() {
     xch_int_.build(*comm_, want_int, dst_int, [&](int64_t g) { const int l = g2l_[g]; return l >= 0 ? intidx_[l] : -1; });
     xch_sep_.build(*comm_, want_sep, dst_sep, [&](int64_t g) { const int l = g2l_[g]; return (l >= 0 && pos2_[l] < n2_) ? pos2_[l] : -1; });
   }
+  lap("A12/A21 + halo plans");
   build_schur_setup();
+  lap("Schur setup + uploads");
   // device residents
   d_krow_ = dev::upload(K_.rowptr); d_kcol_ = dev::upload(K_.col);
   d_kval_ = (double*)dev::alloc(std::max<size_t>(1, K_.val.size()) * sizeof(double));
@@ -556,54 +591,61 @@ void LevelSolver::build_classes() {
     for (int a = 0; a < 3; a++) sd_center_[3 * (size_t)s + a] = m ? (int32_t)(acc[a] / m) : 0;
   }
   sd_xoff_.assign(nsd, 0); sd_cls_.assign(nsd, -1); sd_bidx_.assign(nsd, -1);
-  ivec loc(n, -1);
-  std::unordered_map<uint64_t, std::vector<int>> table;
-  n1_ = 0;
-  in_perm_.clear();
-  for (int s : my_sds_) {
+  (void)n;
+  // ---- pass 1: extended local pattern of every subdomain (in parallel, chunk by chunk), then classification
+  struct SdPat { LocalPattern lp; ivec src, mult, lgptr, key_extra; uint64_t hash = 0; std::string err; };
+  auto build_pattern = [&](int s, SdPat& out) {
     const Subdomain& S = hm_.sd[s];
-    LocalPattern lp;
+    LocalPattern& lp = out.lp;
     lp.nI = (int32_t)S.interior.size();
     lp.nS = S.num_sep();
     ivec ext_rows;  // local nodes of the extended local numbering
     ext_rows.reserve(lp.nI + lp.nS);
     for (int32_t g : S.interior) ext_rows.push_back(g2l_[g]);
-    ivec lgptr(1, 0), key_extra;
+    out.lgptr.assign(1, 0);
     for (auto& g : S.groups) {
       for (int32_t x : g.nodes) ext_rows.push_back(g2l_[x]);
-      lgptr.push_back((int32_t)ext_rows.size() - lp.nI);
-      key_extra.push_back(g.type);
+      out.lgptr.push_back((int32_t)ext_rows.size() - lp.nI);
+      out.key_extra.push_back(g.type);
     }
-    for (auto& L : S.linked) { key_extra.push_back(-7); key_extra.insert(key_extra.end(), L.begin(), L.end()); }
+    for (auto& L : S.linked) { out.key_extra.push_back(-7); out.key_extra.insert(out.key_extra.end(), L.begin(), L.end()); }
     const int ne = lp.nI + lp.nS;
+    // node -> position in this subdomain: small open-addressing table (thread-private)
+    int cap = 16;
+    while (cap < 2 * ne + 2) cap <<= 1;
+    ivec hk(cap, -1), hv(cap, -1);
+    auto find = [&](int32_t node) {
+      uint32_t h = ((uint32_t)node * 2654435761u) & (cap - 1);
+      while (hk[h] != -1) { if (hk[h] == node) return hv[h]; h = (h + 1) & (cap - 1); }
+      return -1;
+    };
     for (int i = 0; i < ne; i++) {
-      HYMLS_CHECK(ext_rows[i] >= 0 && ext_rows[i] < nrows_ && loc[ext_rows[i]] < 0, -3, "node listed twice in a subdomain or without a row");
-      loc[ext_rows[i]] = i;
+      if (!(ext_rows[i] >= 0 && ext_rows[i] < nrows_) || find(ext_rows[i]) >= 0) { out.err = "node listed twice in a subdomain or without a row"; return; }
+      uint32_t h = ((uint32_t)ext_rows[i] * 2654435761u) & (cap - 1);
+      while (hk[h] != -1) h = (h + 1) & (cap - 1);
+      hk[h] = ext_rows[i]; hv[h] = i;
     }
     lp.rowptr.assign(ne + 1, 0);
     lp.zero_diag.assign(lp.nI, 1);
-    ivec src, mult;
     for (int i = 0; i < ne; i++) {
       const int r = ext_rows[i];
       for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
-        const int c = K_.col[e], lc = loc[c];
+        const int c = K_.col[e], lc = find(c);
         if (lc < 0) {
-          HYMLS_CHECK(!(i < lp.nI && pos2_[c] < 0), -2,
-                      "partitioning does not decouple the interiors of different subdomains");
+          if (i < lp.nI && pos2_[c] < 0) { out.err = "partitioning does not decouple the interiors of different subdomains"; return; }
           continue;
         }
         int m = 1;
         if (i >= lp.nI && lc >= lp.nI) {
           m = common(pos2_[r], pos2_[c]);
-          HYMLS_CHECK(m > 0, -3, "separator coupling not inside any subdomain");
+          if (m <= 0) { out.err = "separator coupling not inside any subdomain"; return; }
         }
-        lp.col.push_back(lc); src.push_back(e); mult.push_back(m);
+        lp.col.push_back(lc); out.src.push_back(e); out.mult.push_back(m);
         lp.weight.push_back(1.0 / m);
         if (lc == i && i < lp.nI && K_.val[e] != 0.0) lp.zero_diag[i] = 0;
       }
       lp.rowptr[i + 1] = (int32_t)lp.col.size();
     }
-    for (int i = 0; i < ne; i++) loc[ext_rows[i]] = -1;
     // relative coordinates
     lp.coord.resize(3 * (size_t)lp.nI);
     int32_t mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
@@ -614,34 +656,61 @@ void LevelSolver::build_classes() {
     for (int i = 0; i < lp.nI; i++) for (int a = 0; a < 3; a++) lp.coord[3 * (size_t)i + a] -= mn[a] & ~1;
     Hasher H;
     H.add(&lp.nI, 4); H.add(&lp.nS, 4);
-    H.addv(lp.rowptr); H.addv(lp.col); H.addv(lp.zero_diag); H.addv(lp.coord); H.addv(mult);
-    H.addv(lgptr); H.addv(key_extra);
-    int cid = -1;
-    for (int c : table[H.h]) {
-      Cls& C = *cls_[c];
-      if (C.pat.nI == lp.nI && C.pat.nS == lp.nS && C.pat.rowptr == lp.rowptr && C.pat.col == lp.col &&
-          C.pat.zero_diag == lp.zero_diag && C.pat.coord == lp.coord && C.mult == mult && C.lgptr == lgptr &&
-          C.key_extra == key_extra) { cid = c; break; }
+    H.addv(lp.rowptr); H.addv(lp.col); H.addv(lp.zero_diag); H.addv(lp.coord); H.addv(out.mult);
+    H.addv(out.lgptr); H.addv(out.key_extra);
+    out.hash = H.h;
+  };
+  std::unordered_map<uint64_t, std::vector<int>> table;
+  const size_t first_new = cls_.size();
+  constexpr int64_t CHUNK = 512;
+  for (int64_t c0 = 0; c0 < (int64_t)my_sds_.size(); c0 += CHUNK) {
+    const int64_t c1 = std::min<int64_t>(c0 + CHUNK, (int64_t)my_sds_.size());
+    std::vector<SdPat> pats((size_t)(c1 - c0));
+    parallel_for(c1 - c0, [&](int64_t k) { build_pattern(my_sds_[c0 + k], pats[k]); }, 1);
+    for (int64_t k = 0; k < c1 - c0; k++) {
+      SdPat& Pt = pats[k];
+      HYMLS_CHECK(Pt.err.empty(), Pt.err.find("decouple") != std::string::npos ? -2 : -3, Pt.err);
+      const int s = my_sds_[c0 + k];
+      const Subdomain& S = hm_.sd[s];
+      LocalPattern& lp = Pt.lp;
+      int cid = -1;
+      for (int c : table[Pt.hash]) {
+        Cls& C = *cls_[c];
+        if (C.pat.nI == lp.nI && C.pat.nS == lp.nS && C.pat.rowptr == lp.rowptr && C.pat.col == lp.col &&
+            C.pat.zero_diag == lp.zero_diag && C.pat.coord == lp.coord && C.mult == Pt.mult && C.lgptr == Pt.lgptr &&
+            C.key_extra == Pt.key_extra) { cid = c; break; }
+      }
+      if (cid < 0) {
+        cid = (int)cls_.size();
+        cls_.emplace_back(new Cls());
+        Cls& C = *cls_.back();
+        C.pat = std::move(lp);
+        C.mult = Pt.mult; C.lgptr = Pt.lgptr; C.key_extra = Pt.key_extra;
+        C.llinked = S.linked;
+        C.ngl = (int32_t)S.groups.size();
+        table[Pt.hash].push_back(cid);
+      }
+      Cls& C = *cls_[cid];
+      sd_cls_[s] = cid;
+      sd_bidx_[s] = (int32_t)C.lu.members.size();
+      C.lu.members.push_back(s);
+      // map the class's entry numbering (plan.ent_id refers to the extended CSR) onto this member
+      C.lu.h_src.insert(C.lu.h_src.end(), Pt.src.begin(), Pt.src.end());
     }
-    if (cid < 0) {
-      cid = (int)cls_.size();
-      cls_.emplace_back(new Cls());
-      Cls& C = *cls_.back();
-      C.lu.plan = analyse_class(lp, LEAF_SIZE, MAX_WIDTH);
-      C.pat = std::move(lp);
-      C.mult = mult; C.lgptr = lgptr; C.key_extra = key_extra;
-      C.llinked = S.linked;
-      C.ngl = (int32_t)S.groups.size();
-      table[H.h].push_back(cid);
-    }
-    Cls& C = *cls_[cid];
-    sd_cls_[s] = cid;
-    sd_bidx_[s] = (int32_t)C.lu.members.size();
+  }
+  // ---- pass 2: symbolic analysis of every class (independent: in parallel)
+  parallel_for((int64_t)(cls_.size() - first_new), [&](int64_t k) {
+    Cls& C = *cls_[first_new + k];
+    C.lu.plan = analyse_class(C.pat, LEAF_SIZE, MAX_WIDTH);
+  }, 1);
+  // ---- pass 3: interior numbering in elimination order, subdomain by subdomain
+  n1_ = 0;
+  in_perm_.clear();
+  for (int s : my_sds_) {
+    const Subdomain& S = hm_.sd[s];
+    Cls& C = *cls_[sd_cls_[s]];
     sd_xoff_[s] = n1_;
-    C.lu.members.push_back(s);
     C.lu.h_xoff.push_back(n1_);
-    // map the class's entry numbering (plan.ent_id refers to the extended CSR) onto this member
-    C.lu.h_src.insert(C.lu.h_src.end(), src.begin(), src.end());
     for (int t = 0; t < C.pat.nI; t++) {
       const int r = g2l_[S.interior[C.lu.plan.perm[t]]];
       in_perm_.push_back(r);
@@ -768,11 +837,29 @@ void LevelSolver::build_schur_setup() {
     contributors.insert(contributors.end(), halo_list.begin(), halo_list.end());
     std::sort(contributors.begin(), contributors.end());   // subdomain order, as on one rank
   }
-  // ---- pull lists
-  struct Coo { int64_t row, colgid, src; };
-  std::vector<Coo> coo;
+  // ---- pull lists.  Entries (row, column gid, source position) are bucketed by row with a counting pass,
+  // packed as (column gid << 33 | source) and sorted row by row in parallel.
+  HYMLS_CHECK(ext_total_ < ((int64_t)1 << 33), -2, "extraction buffer too large for the packed pull keys");
+  std::vector<int64_t> rcount;
+  std::vector<uint64_t> keys;
+  std::vector<int64_t> rfill;
+  int pass = 0;
+  auto emit = [&](int64_t row, int64_t colgid, int64_t src) {
+    if (pass == 0) rcount[row + 1]++;
+    else keys[rfill[row]++] = ((uint64_t)colgid << 33) | (uint64_t)src;
+  };
+  red_.n = direct_schur_ ? n2_ : ng_owned;
+  rcount.assign((size_t)red_.n + 1, 0);
+  std::map<int32_t, int> bc_of_size;
+  std::unordered_map<int32_t, std::pair<int, int>> block_of_key;  // first group's vsum gid -> (class, index)
+  std::vector<std::vector<std::vector<int64_t>>> contrib;
+  for (pass = 0; pass < 2; pass++) {
+  if (pass == 1) {
+    for (int64_t r = 0; r < red_.n; r++) rcount[r + 1] += rcount[r];
+    keys.resize((size_t)rcount[red_.n]);
+    rfill.assign(rcount.begin(), rcount.end() - 1);
+  }
   if (direct_schur_) {
-    red_.n = n2_;
     for (auto& ct : contributors) {
       const Subdomain& S = hm_.sd[ct.first];
       const int nS = S.num_sep();
@@ -780,9 +867,9 @@ void LevelSolver::build_schur_setup() {
       for (auto& g : S.groups) for (int32_t x : g.nodes) { gp.push_back(owned_sep(x)); gg.push_back(x); }
       for (int b = 0; b < nS; b++)
         for (int a = 0; a < nS; a++)
-          if (gp[a] >= 0) coo.push_back({gp[a], gg[b], ct.second + a + (int64_t)nS * b});
+          if (gp[a] >= 0) emit(gp[a], gg[b], ct.second + a + (int64_t)nS * b);
     }
-  } else {
+  } else if (pass == 0) {
     // Householder rows (InitializeOT, reference src/HYMLS_SchurPreconditioner.cpp:384-467 +
     // Householder::Construct, src/HYMLS_Householder.cpp:128-163)
     otw_.assign(n2_, 0.0);
@@ -804,8 +891,6 @@ void LevelSolver::build_schur_setup() {
       for (int i = b; i < e; i++) otw_[i] = v[i - b] / nrm2;
     }
     // dense blocks: one per owned linked set with at least one non-V-sum row
-    std::map<int32_t, int> bc_of_size;
-    std::unordered_map<int32_t, std::pair<int, int>> block_of_key;  // first group's vsum gid -> (class, index)
     for (int s : my_sds_) {
       const Subdomain& S = hm_.sd[s];
       for (auto& L : S.owned_linked) {
@@ -820,9 +905,10 @@ void LevelSolver::build_schur_setup() {
         B.nblk++;
       }
     }
-    std::vector<std::vector<std::vector<int64_t>>> contrib(blocks_.size());
+    contrib.resize(blocks_.size());
     for (size_t c = 0; c < blocks_.size(); c++) contrib[c].resize(blocks_[c].nblk);
-    red_.n = ng_owned;
+  }
+  if (!direct_schur_) {
     for (auto& ct : contributors) {
       const Subdomain& S = hm_.sd[ct.first];
       const bool local = sd_rank_[ct.first] == comm_->rank;
@@ -836,9 +922,12 @@ void LevelSolver::build_schur_setup() {
         if (vg[a] >= 0)
           HYMLS_CHECK(gptr_[vg[a] + 1] - gptr_[vg[a]] == (int)S.groups[a].nodes.size(), -3, "group differs between subdomains");
       }
-      for (int b = 0; b < L.ngl; b++)
-        for (int a = 0; a < L.ngl; a++)
-          if (vg[a] >= 0) coo.push_back({vg[a], S.groups[b].nodes[0], base + a + (int64_t)L.ngl * b});
+      for (int a = 0; a < L.ngl; a++)
+        if (vg[a] >= 0) {
+          if (pass == 0) rcount[vg[a] + 1] += L.ngl;
+          else for (int b = 0; b < L.ngl; b++) emit(vg[a], S.groups[b].nodes[0], base + a + (int64_t)L.ngl * b);
+        }
+      if (pass == 1) continue;
       for (size_t li = 0; li < S.linked.size(); li++) {
         if (L.blk_off[li] < 0) continue;
         auto it = block_of_key.find(S.groups[S.linked[li][0]].nodes[0]);
@@ -856,6 +945,9 @@ void LevelSolver::build_schur_setup() {
       }
       (void)local;
     }
+  }
+  }  // passes
+  if (!direct_schur_) {
     for (size_t c = 0; c < blocks_.size(); c++) {
       BlockClass& B = blocks_[c];
       B.pull_ptr.assign(1, 0);
@@ -868,25 +960,28 @@ void LevelSolver::build_schur_setup() {
     d_vrhs_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
     d_vsol_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
   }
-  // COO -> CSR pattern (columns = gids) with pull lists
-  std::sort(coo.begin(), coo.end(), [](const Coo& a, const Coo& b) {
-    if (a.row != b.row) return a.row < b.row;
-    if (a.colgid != b.colgid) return a.colgid < b.colgid;
-    return a.src < b.src;
-  });
+  // buckets -> CSR pattern (columns = gids) with pull lists: sort every row (column gid, then source position)
   const int64_t nr = red_.n;
-  red_.rowptr.assign(nr + 1, 0); red_.col.clear();
-  red_pull_ptr_.assign(1, 0); red_pull_idx_.clear();
-  red_pull_idx_.reserve(coo.size());
-  for (size_t k = 0; k < coo.size();) {
-    size_t k2 = k;
-    while (k2 < coo.size() && coo[k2].row == coo[k].row && coo[k2].colgid == coo[k].colgid) { red_pull_idx_.push_back(coo[k2].src); k2++; }
-    red_.col.push_back((int32_t)coo[k].colgid);
-    red_.rowptr[coo[k].row + 1]++;
-    red_pull_ptr_.push_back((int64_t)red_pull_idx_.size());
-    k = k2;
-  }
+  red_.rowptr.assign(nr + 1, 0);
+  parallel_for(nr, [&](int64_t r) {
+    std::sort(keys.begin() + rcount[r], keys.begin() + rcount[r + 1]);
+    int32_t nu = 0;
+    for (int64_t k = rcount[r]; k < rcount[r + 1]; k++) nu += k == rcount[r] || (keys[k] >> 33) != (keys[k - 1] >> 33);
+    red_.rowptr[r + 1] = nu;
+  });
   for (int64_t r = 0; r < nr; r++) red_.rowptr[r + 1] += red_.rowptr[r];
+  red_.col.assign((size_t)red_.rowptr[nr], 0);
+  red_pull_ptr_.assign((size_t)red_.rowptr[nr] + 1, 0);
+  red_pull_idx_.resize(keys.size());
+  parallel_for(nr, [&](int64_t r) {
+    int64_t e = red_.rowptr[r] - 1;
+    for (int64_t k = rcount[r]; k < rcount[r + 1]; k++) {
+      if (k == rcount[r] || (keys[k] >> 33) != (keys[k - 1] >> 33)) { e++; red_.col[e] = (int32_t)(keys[k] >> 33); }
+      red_pull_idx_[k] = (int64_t)(keys[k] & (((uint64_t)1 << 33) - 1));
+      red_pull_ptr_[e + 1] = k + 1;
+    }
+  });
+  { std::vector<uint64_t>().swap(keys); }
   red_.val.assign(red_.col.size(), 0.0);
   d_red_pull_ptr_ = dev::upload(red_pull_ptr_); d_red_pull_idx_ = dev::upload(red_pull_idx_);
   d_red_val_ = (double*)dev::alloc(std::max<size_t>(1, red_.col.size()) * sizeof(double));
@@ -1086,6 +1181,14 @@ void LevelSolver::build_handoff(const ivec& next_owned) {
 void LevelSolver::compute() {
   HYMLS_CHECK(initialized_, -1, "level not initialized");
   const bool dist = comm_->distributed();
+  const bool verbose = std::getenv("HYMLS_MI_VERBOSE") != nullptr;
+  double t0 = wall();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    dev::sync();
+    std::fprintf(stderr, "[hymls_mi] rank %d level %d compute: %-28s %.2f s\n", comm_->rank, level_, what, wall() - t0);
+    t0 = wall();
+  };
   dev::h2d(d_kval_, K_.val.data(), K_.val.size() * sizeof(double));
   dev::gather((int64_t)a12_col_.size(), d_a12_src_, d_kval_, d_a12_val_);
   dev::gather((int64_t)a21_col_.size(), d_a21_src_, d_kval_, d_a21_val_);
@@ -1109,6 +1212,7 @@ void LevelSolver::compute() {
   // (collective: every rank has to reach the exchanges below, so errors are agreed on first)
   HYMLS_CHECK(comm_->allsum(bad) == 0, -4, "subdomain factorisation hit a zero or non-finite pivot (level " +
                                                std::to_string(level_) + ")");
+  lap("factor + transform + extract");
   exchange_records();
   // ---- assemble what is kept of the Schur complement
   dev::pull_sum((int64_t)red_.col.size(), d_red_pull_ptr_, d_red_pull_idx_, d_ext_, d_red_val_);
@@ -1152,8 +1256,10 @@ void LevelSolver::compute() {
       tvn[g] = 2.0 * otw_[gptr_[g]] * dot - tv_[sep_row_[gptr_[g]]];
     }
   }
+  lap("pull + separator blocks");
   assemble_reduced(G, next_gids, &tvn);
   Csr R = drop_by_value(G, SMALL_ENTRY, 0);
+  lap("reduced matrix (host)");
   if (level_ + 1 < p_.levels) {
     next_is_direct_ = false;
     if (next_level_ && next_pattern_key_rowptr_ == R.rowptr && next_pattern_key_col_ == R.col) {
@@ -1167,7 +1273,9 @@ void LevelSolver::compute() {
       build_handoff(next_level_->owned_gids());
     }
     next_level_->profiling = false;  // phases are reported for the top level only
+    lap("next level initialize");
     next_level_->compute();
+    lap("next level compute");
   } else {
     next_level_ = nullptr;
     next_is_direct_ = true;
@@ -1182,6 +1290,7 @@ void LevelSolver::compute() {
       next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &cp, &cl, &sd_center_));
     }
     build_handoff(next_gids);
+    lap("coarse solver");
   }
 }
 

@@ -21,7 +21,7 @@ def _free_port():
 def _run(nproc, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--grid", "8", "--sx", "4", "--hostsim", "--no-cpu-baseline"]
+           "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--grid", "16", "--sx", "4", "--levels", "1", "--hostsim", "--no-cpu-baseline"]
     cmd += list(extra)
     env = dict(os.environ, OMP_NUM_THREADS="1")
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -32,12 +32,12 @@ def _run(nproc, extra=()):
 
 
 def test_bench_two_ranks_sharded_gloo():
-    r = _run(2, ["--levels", "1"])
+    r = _run(2)
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1
-    assert r["unit"] == "DoF/s" and r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["unit"] == "DoF/s" and r["higher_is_better"] is True and r["scaling"] == "strong" and r["vs_baseline"] is None
     assert r["dtype"] == "f64" and "TEST ONLY" in r["data"]
-    assert "sharded: 2x1x1 boxes" in r["config"]["parallelism"] and "16x8x8" in r["config"]["workload"]
-    assert r["config"]["levels"][0][1] == 16 * 8 * 8 * 4      # the global problem, not one box
+    assert "sharded: 2x1x1 boxes of 8x16x16" in r["config"]["parallelism"] and "16x16x16" in r["config"]["workload"]
+    assert r["config"]["levels"][0][1] == 16 * 16 * 16 * 4      # the one global problem, split over the ranks
     assert r["value"] > 0 and r["ms_per_step"] > 0
     assert set(r["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert r["cpu_baseline"] is None   # rank 0 at N=1 only
@@ -45,7 +45,7 @@ def test_bench_two_ranks_sharded_gloo():
 
 def test_bench_two_ranks_replicas_gloo():
     r = _run(2, ["--replicas"])
-    assert r["n_gpus"] == 2
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak"
     assert "2 replicas" in r["config"]["parallelism"] and "workload" in r["config"]
     assert r["value"] > 0 and r["ms_per_step"] > 0
     assert set(r["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}

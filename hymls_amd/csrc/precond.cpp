@@ -353,13 +353,15 @@ void LevelSolver::partition(const ivec* level_gids) {
               bz = (p_.nz + comm_->pz - 1) / comm_->pz;
     const int rx = comm_->rank % comm_->px, ry = (comm_->rank / comm_->px) % comm_->py, rz = comm_->rank / (comm_->px * comm_->py);
     const int mx = 2 * p_.sx + 3, my = 2 * p_.sy + 3, mz = 2 * p_.sz + 3;
+    // few subdomains (coarser levels): no geometric prefilter, every subdomain is a halo candidate
+    const int all_below = std::getenv("HYMLS_MI_HALO_ALL_BELOW") ? std::atoi(std::getenv("HYMLS_MI_HALO_ALL_BELOW")) : 4096;
     for (int s = 0; s < nsd; s++) {
       int x, y, z;
       sd_position(p_, s, x, y, z);
       const int cx = std::min(std::max(x, 0), p_.nx - 1), cy = std::min(std::max(y, 0), p_.ny - 1),
                 cz = std::min(std::max(z, 0), p_.nz - 1);
       sd_rank_[s] = ((cz / bz) * comm_->py + cy / by) * comm_->px + cx / bx;
-      cand[s] = nsd <= 4096 || (x >= rx * bx - mx && x < (rx + 1) * bx + mx && y >= ry * by - my && y < (ry + 1) * by + my &&
+      cand[s] = nsd <= all_below || (x >= rx * bx - mx && x < (rx + 1) * bx + mx && y >= ry * by - my && y < (ry + 1) * by + my &&
                                 z >= rz * bz - mz && z < (rz + 1) * bz + mz);
     }
   }

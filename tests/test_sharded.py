@@ -23,11 +23,12 @@ CASES = [
 ]
 
 
-def run_worker(world, args, mode, port, timeout=900):
+def run_worker(world, args, mode, port, timeout=900, env_extra=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
     cmd += [str(a) for a in args] + [mode]
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    env.update(env_extra or {})
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     lines = [l for l in out.stdout.splitlines() if l.startswith("DIST_RESULT ")]
     assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
@@ -41,3 +42,17 @@ def test_sharded_matches_one_rank(hostsim_lib, world, eq, nx, ny, nz, sx, levels
     assert res["levels"] == res["levels_sharded"]
     assert res["rel_err"] < 1e-12
     assert res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12
+
+
+@pytest.mark.parametrize("world,eq,nx,ny,nz,sx,levels,cx,part", [
+    (2, "Stokes-C", 32, 16, 16, 4, 1, -1, "Skew Cartesian"),
+    (8, "Laplace", 32, 32, 32, 4, 2, 2, "Cartesian"),
+])
+def test_sharded_geometric_halo_prefilter(hostsim_lib, world, eq, nx, ny, nz, sx, levels, cx, part):
+    """large grids only look at the subdomains near the rank's box when they build the halo; force that code
+    path on a small grid (HYMLS_MI_HALO_ALL_BELOW=0) -- a halo subdomain that was missed would change ownership
+    or multiplicities and with them the result."""
+    res = run_worker(world, (eq, nx, ny, nz, sx, levels, cx, part), "hostsim", 29560 + world,
+                     env_extra={"HYMLS_MI_HALO_ALL_BELOW": "0"})
+    assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
+    assert res["rel_err"] < 1e-12

@@ -43,3 +43,32 @@ def product_prec(A, tv, prm, lib):
 
 def rel_diff(x, y):
     return np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-300)
+
+
+def add_convection(A, n, re=50.0, nz=None):
+    """Stokes3D Jacobian + a linearised convection term (BASELINE configs[3] in the small: a Navier-Stokes-like,
+    NONSYMMETRIC F-matrix): for every velocity-velocity coupling to the neighbour in direction d the central
+    difference of w_d * du/dx_d is added (+g to the next, -g to the previous neighbour), with w a fixed swirling
+    field and g = re / (2 n) * a / n (cell Reynolds number re / n relative to the diffusion coefficient).
+    Gradient and divergence blocks are untouched, the sparsity pattern does not change."""
+    nz = n if nz is None else nz
+    A = A.tocsr().copy()
+    A.sort_indices()
+    rows = np.repeat(np.arange(A.shape[0]), np.diff(A.indptr))
+    cols = A.indices
+    var_r, var_c = rows % 4, cols % 4
+    cell_r, cell_c = rows // 4, cols // 4
+    step = {1: 0, n: 1, n * n: 2}
+    diff = cell_c - cell_r
+    i, j, k = cell_r % n, (cell_r // n) % n, cell_r // (n * n)
+    x, y, z = (i + 0.5) / n - 0.5, (j + 0.5) / n - 0.5, (k + 0.5) / nz - 0.5
+    w = np.stack([-y + 0.3 * z, x - 0.2 * z, 0.5 * x * y])       # swirling, not divergence-free on purpose
+    a_diff = float(n * n)
+    g = re / (2.0 * n) * a_diff / n
+    data = A.data.copy()
+    for st, d in step.items():
+        for sgn in (+1, -1):
+            m = (var_r < 3) & (var_r == var_c) & (diff == sgn * st) & (A.data != 0)
+            data[m] += sgn * g * w[d][m]
+    A.data = data
+    return A

@@ -131,3 +131,32 @@ def test_merged_level_solve_path(hostsim_lib, monkeypatch, small_rows):
     O = oracle_prec(A, tv, "Stokes-C", 16, 8, 1, partitioner="Skew Cartesian")
     b = np.random.default_rng(12).uniform(-1, 1, A.shape[0])
     assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-9
+
+
+@pytest.mark.parametrize("levels,tol", [(0, 1e-9), (1, 1e-8)])
+def test_nonsymmetric_navier_stokes_like(hostsim_lib, levels, tol):
+    """unsymmetric values (convection) on the Stokes pattern: the LU without pivoting and the separate L- and
+    U-side panels against the oracle (SuperLU with partial pivoting)."""
+    from common import add_convection
+    n = 16
+    A, tv = problem("Stokes-C", n)
+    A = add_convection(A, n, re=80.0)
+    assert abs(A - A.T).max() > 1.0
+    P = product_prec(A, tv, xml_params("Stokes-C", n, 8, levels, partitioner="Skew Cartesian"), hostsim_lib)
+    O = oracle_prec(A, tv, "Stokes-C", n, 8, levels, partitioner="Skew Cartesian")
+    b = np.random.default_rng(21).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < tol
+
+
+@pytest.mark.parametrize("levels", [0, 1])
+def test_darcy3d_saddle_point(hostsim_lib, levels):
+    """GaleriExt Darcy3D (BASELINE configs[4] in the small; Equations=Stokes-C as SURVEY 8d notes): velocities
+    couple only through the pressures."""
+    from oracle import galeri
+    n = 16
+    A = galeri.darcy3d(n, n, n, 1.0, -1.0)
+    tv = galeri.create_testvector(A)
+    P = product_prec(A, tv, xml_params("Stokes-C", n, 8, levels, partitioner="Skew Cartesian"), hostsim_lib)
+    O = oracle_prec(A, tv, "Stokes-C", n, 8, levels, partitioner="Skew Cartesian")
+    b = np.random.default_rng(22).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-8

@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--sx", type=int, default=8)
     ap.add_argument("--levels", type=int, default=2, help="XML 'Number of Levels' (2 = the 3-level method)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies instead of the sharded problem")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="N = 1: take the sharded code path anyway (one rank exchanging with itself over the transport): "
+                         "measures what packing + callbacks + collectives cost per ApplyInverse")
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -93,7 +96,10 @@ def main():
         assert torch.cuda.is_available(), "bench.py needs a GPU (hymls_amd has no CPU fallback)"
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if args.force_sharded and world == 1:
+        os.environ["HYMLS_MI_FORCE_SHARDED"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29577"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -102,7 +108,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     n, sx = args.n, args.sx
-    sharded = world > 1 and not args.replicas
+    sharded = (world > 1 and not args.replicas) or args.force_sharded
     note = None
     if sharded:
         # self-test of the transport on this backend (uneven all-to-all on the library's stream); if any rank
@@ -236,7 +242,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -133,6 +133,7 @@ int hymls_mi_set_comm(hymls_mi_t* h, const hymls_mi_comm* c, int px, int py, int
   h->comm.rank = c->rank; h->comm.size = c->size; h->comm.ctx = c->ctx;
   h->comm.px = px; h->comm.py = py; h->comm.pz = pz;
   h->comm.alltoallv = c->alltoallv; h->comm.alloc = c->alloc;
+  h->comm.force = c->size == 1 && c->alltoallv && c->alloc && std::getenv("HYMLS_MI_FORCE_SHARDED") != nullptr;
   h->top.reset(); h->initialized = false; h->computed = false; h->have_matrix = false;
   API_END(h)
 }

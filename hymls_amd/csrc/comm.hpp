@@ -24,7 +24,8 @@ struct Comm {
   // exchange arena the transport can address (a torch tensor in the Python mirror)
   void* (*alloc)(void* ctx, int64_t bytes) = nullptr;
 
-  bool distributed() const { return size > 1; }
+  bool force = false;           // treat a single rank as sharded (exercises the transport with self-exchanges)
+  bool distributed() const { return size > 1 || force; }
 
   // ---- host helpers (setup time)
   void a2a_host(const void* send, const std::vector<int64_t>& scnt, void* recv, const std::vector<int64_t>& rcnt,

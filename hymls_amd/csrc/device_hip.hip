@@ -1219,16 +1219,21 @@ void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, c
 // is read with consecutive rows on consecutive lanes; with few items the k range is split over
 // 2 or 4 thread groups so that small levels still keep many loads in flight.
 struct FusedFront { int32_t c0, w, ri, c_off, a_off, lf_off, idx_off, pad; int64_t lp_off, q_off; };
-__global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
-                                                         double* __restrict__ x) {
+template <bool PROF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
+                                                         double* __restrict__ x, long long* __restrict__ prof) {
   extern __shared__ double lds[];
+  long long tp[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, tstart = 0;
+  auto tick = [&](int bucket) { if (PROF) { const long long t = wall_clock64(); tp[bucket] += t - t0; t0 = t; } };
+  if (PROF) { t0 = wall_clock64(); tstart = t0; }
   const FusedSub S = subs[blockIdx.x];
   const PlanD P = plans[S.cls];
   double* X = lds;
   double* C = lds + P.nI;
   double* Fv = C + P.contrib_size;
-  double* R = Fv + P.max_level_rows;
-  FusedFront* LF = (FusedFront*)(R + 256);     // compact front descriptors of the class, cached in LDS
+  // reduction scratch of the k-split levels (<= 128 items, so F uses at most its first 128 entries there): inside F
+  double* R = Fv + 128;
+  FusedFront* LF = (FusedFront*)(Fv + (P.max_level_rows > 384 ? P.max_level_rows : 384));   // compact front descriptors, cached in LDS
   const int tid = threadIdx.x;
   for (int i = tid; i < P.nfronts; i += 256) {
     const FrontD G = P.fronts[i];
@@ -1240,6 +1245,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
   double* xg = x + S.xoff;
   for (int i = tid; i < P.nI; i += 256) X[i] = xg[i];
   __syncthreads();
+  tick(0);
   const double* __restrict__ fac = S.fac;
   // ---------------- forward (leaves to root)
   for (int lev = 0; lev < P.nlev; lev++) {
@@ -1253,6 +1259,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
       if (r < F.w) Fv[F.lf_off + r] = v; else C[F.c_off + r - F.w] = v;   // update rows are assembled in place
     }
     __syncthreads();
+    tick(1);
     if (ni > 128) {
       for (int it = tid; it < ni; it += 256) {
         const int item = P.fw_items[ib + it];
@@ -1308,6 +1315,7 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
       }
     }
     __syncthreads();
+    tick(2);
   }
   // ---------------- backward (root to leaves)
   for (int lev = P.nlev - 1; lev >= 0; lev--) {
@@ -1387,15 +1395,38 @@ __global__ void __launch_bounds__(256) k_interior_fused(const FusedSub* __restri
       }
     }
     __syncthreads();
+    tick(ni > 128 ? 3 : 4);
   }
   for (int i = tid; i < P.nI; i += 256) xg[i] = X[i];
+  if (PROF && tid == 0) {
+    tp[5] = wall_clock64() - tstart;
+    for (int q = 0; q < 6; q++) prof[(int64_t)blockIdx.x * 8 + q] = tp[q];
+    prof[(int64_t)blockIdx.x * 8 + 6] = tstart;
+    prof[(int64_t)blockIdx.x * 8 + 7] = P.nI;
+  }
 }
 
 void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, double* x) {
   if (nsub <= 0) return;
   const size_t shm = (size_t)lds_doubles * sizeof(double);
-  if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(k_interior_fused, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x);
+  if (std::getenv("HYMLS_MI_FUSED_PROF")) {
+    // development aid: per-phase wall-clock ticks (100 MHz) of every workgroup, averaged, on stderr
+    long long* dprof = (long long*)alloc((size_t)nsub * 8 * sizeof(long long));
+    if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(k_interior_fused<true>, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, dprof);
+    launch_check();
+    std::vector<long long> h((size_t)nsub * 8);
+    d2h(h.data(), dprof, h.size() * sizeof(long long));
+    free(dprof);
+    double sum[6] = {0, 0, 0, 0, 0, 0};
+    long long tmin = h[6], tmax = 0;
+    for (int b = 0; b < nsub; b++) { for (int q = 0; q < 6; q++) sum[q] += (double)h[(size_t)b * 8 + q]; tmin = std::min(tmin, h[(size_t)b * 8 + 6]); tmax = std::max(tmax, h[(size_t)b * 8 + 6] + h[(size_t)b * 8 + 5]); }
+    std::fprintf(stderr, "[hymls_mi] fused solve: %d workgroups, kernel span %.1f us; mean per workgroup (us): setup %.1f | fwd assembly %.1f | fwd panels %.1f | bwd panels (wide levels) %.1f | bwd panels (k-split levels) %.1f | total %.1f\n",
+                 nsub, (tmax - tmin) / 100.0, sum[0] / nsub / 100, sum[1] / nsub / 100, sum[2] / nsub / 100, sum[3] / nsub / 100, sum[4] / nsub / 100, sum[5] / nsub / 100);
+    return;
+  }
+  if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_interior_fused<false>, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, (long long*)nullptr);
   launch_check();
 }
 

@@ -703,7 +703,7 @@ void LevelSolver::build_classes() {
   // ---- pass 2: symbolic analysis of every class (independent: in parallel)
   parallel_for((int64_t)(cls_.size() - first_new), [&](int64_t k) {
     Cls& C = *cls_[first_new + k];
-    C.lu.plan = analyse_class(C.pat, LEAF_SIZE, MAX_WIDTH);
+    C.lu.plan = analyse_class(C.pat, std::getenv("HYMLS_MI_LEAF_SIZE") ? std::atoi(std::getenv("HYMLS_MI_LEAF_SIZE")) : LEAF_SIZE, MAX_WIDTH);
   }, 1);
   // ---- pass 3: interior numbering in elimination order, subdomain by subdomain
   n1_ = 0;
@@ -1004,8 +1004,8 @@ void LevelSolver::build_schur_setup() {
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
     plans.push_back(C.lu.dplan);
-    const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + C.lu.plan.max_level_rows + 256 +
-                         (int32_t)(C.lu.plan.fronts.size() * 6 + 1);   // X | C | F | R | compact front descriptors (48 B)
+    const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + std::max(C.lu.plan.max_level_rows, 384) +
+                         (int32_t)(C.lu.plan.fronts.size() * 6 + 1);   // X | C | F (+ R inside) | compact front descriptors (48 B)
     bool any_big = false;
     for (auto& L : C.lu.plan.big_levels) any_big |= !L.empty();
     if (any_big || C.lu.plan.max_level_rows > dev::FUSED_MAX_ITEMS || need > LDS_CAP || C.lu.plan.nI == 0 ||

@@ -22,9 +22,19 @@ def main():
     eq, nx, ny, nz, sx, levels, cx, part, mode = sys.argv[1:10]
     nx, ny, nz, sx, levels, cx = int(nx), int(ny), int(nz), int(sx), int(levels), int(cx)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="gloo")
+    if mode == "gpu-nccl":     # one rank per GPU over RCCL (a single rank exchanges with itself: HYMLS_MI_FORCE_SHARDED)
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+    else:
+        dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    if mode == "hostsim":
+    if mode == "gpu-nccl":
+        lib = hymls_amd.load_library()
+        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+        from hymls_amd.dist import transport_selftest
+        err = transport_selftest(device, "nccl")
+        assert err is None, err
+    elif mode == "hostsim":
         lib = hymls_amd.load_library(os.path.join(ROOT, "tests", "hostsim", "libhymls_mi_hostsim.so"))
         device = "cpu"
     else:
@@ -36,7 +46,8 @@ def main():
     prm = {"Problem": {"Equations": eq, "Dimension": 3, "nx": nx, "ny": ny, "nz": nz}, "Preconditioner": prec}
     a = float(nx * nx)
     comm = TorchComm(device)
-    P = hymls_amd.Preconditioner(None, prm, lib=lib, comm=comm, rank_grid=rank_grid(world))
+    P = hymls_amd.Preconditioner(None, prm, lib=lib, comm=comm, rank_grid=rank_grid(world),
+                                 device=int(os.environ.get("LOCAL_RANK", "0")) if mode == "gpu-nccl" else 0)
     req = P.RequiredRows()
     rows = hymls_amd.generate_rows(eq, nx, ny, nz, req, a=a, lib=lib)
     P.SetMatrixRows(req, rows)

@@ -309,3 +309,16 @@ def test_full_size_properties_128(gpu_lib):
     true_rel = float((rhs - P.MatVec(xs)).norm() / rhs.norm())
     print("GMRES(128^3, 3-level): %d iterations, true relative residual %.2e" % (its, true_rel))
     assert its < 400 and true_rel < 1e-7
+
+
+@pytest.mark.gpu
+def test_sharded_transport_over_rccl_single_rank(gpu_lib):
+    """the RCCL transport itself (dist.all_to_all_single on the library's stream through
+    torch.cuda.ExternalStream, arenas as torch tensors, gloo side group for the host exchanges): one rank that
+    is forced to take the sharded code path and exchanges with itself.  Multi-rank RCCL needs one GPU per
+    rank and is exercised by bench.py --gpus N on a multi-GPU node."""
+    from test_sharded import run_worker
+    res = run_worker(1, ("Stokes-C", 32, 32, 32, 4, 2, 2, "Skew Cartesian"), "gpu-nccl", 29551, timeout=600,
+                     env_extra={"HYMLS_MI_FORCE_SHARDED": "1"})
+    assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
+    assert res["rel_err"] < 1e-10 and res["repeat_diff"] == 0.0

@@ -66,6 +66,7 @@ struct PlanD {
   int64_t scratch_size, factor_size;
   int32_t contrib_size;
   int32_t max_solve_rows;   // max over fronts of w + ri (LDS vector of the solve kernels)
+  int32_t packed;           // L-side panels of this class are repacked (see repack_fronts)
 };
 
 // a batch of subdomains of one class
@@ -121,6 +122,24 @@ void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const F
 // ---- solves with the factor panels; x is the level vector (interior part), in place
 void solve_fwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x);
 void solve_bwd_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, double* x);
+
+// ---- packed panels (classes solved by the fused kernel).  The factorisation leaves per front the
+// column-major (w+ri) x w panel [L11^{-1} strictly lower \ U11^{-1} upper ; L21 L11^{-1}]; a sweep only ever
+// needs one of the two triangles, and reading a triangle out of the tall columns drags the other one's
+// cache lines along.  repack_fronts rearranges the same (w+ri) w entries in place into three contiguous
+// pieces, so that each sweep streams only bytes it uses:
+//   [ strictly lower triangle, packed by columns : w(w-1)/2 | L21 L11^{-1}, ri x w, ld = ri | upper
+//     triangle incl. diagonal, packed by columns : w(w+1)/2 ]            (the U-side panel Q stays where it is)
+#if defined(__HIPCC__)
+#define HYMLS_HD __host__ __device__
+#else
+#define HYMLS_HD
+#endif
+HYMLS_HD inline int64_t packed_lower(int64_t w, int64_t i, int64_t k) { return k * (2 * w - k - 1) / 2 + (i - k - 1); }   // i > k
+HYMLS_HD inline int64_t packed_l21(int64_t w, int64_t ri, int64_t i, int64_t k) { return w * (w - 1) / 2 + i + ri * k; }      // row i of L21
+HYMLS_HD inline int64_t packed_upper(int64_t w, int64_t ri, int64_t i, int64_t k) { return w * (w - 1) / 2 + ri * w + k * (k + 1) / 2 + i; }  // i <= k
+// members [b0, b0+nbc) of the batch; uses the frontal scratch of the chunk as temporary
+void repack_fronts(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc);
 
 // ---- fused interior solve: one workgroup per subdomain walks its whole assembly tree
 // (forward then backward) with the solution vector and all contribution vectors in LDS;

@@ -1209,6 +1209,29 @@ void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, c
   launch_check();
 }
 
+// ------------------------------------------------------------------ packed panels
+// one workgroup per (front, member): copy the (w+ri) x w panel to the frontal scratch of the member's slot,
+// write it back in the packed order (device.hpp)
+__global__ void __launch_bounds__(256) k_repack(PlanD P, BatchD B, int32_t b0) {
+  const FrontD F = P.fronts[blockIdx.x];
+  const int slot = blockIdx.y, b = b0 + slot;
+  const int64_t w = F.w, ri = F.ri, ld = w + ri, n = ld * w;
+  double* Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off;
+  double* tmp = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;   // this front's own frontal matrix: (w+ri+rs)^2 >= (w+ri) w
+  for (int64_t t = threadIdx.x; t < n; t += 256) tmp[t] = Lp[t];
+  __syncthreads();
+  for (int64_t t = threadIdx.x; t < n; t += 256) {
+    const int64_t i = t % ld, k = t / ld;
+    const int64_t dst = i >= w ? packed_l21(w, ri, i - w, k) : (i > k ? packed_lower(w, i, k) : packed_upper(w, ri, i, k));
+    Lp[dst] = tmp[t];
+  }
+}
+void repack_fronts(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc) {
+  if (P.nfronts <= 0 || nbc <= 0) return;
+  hipLaunchKernelGGL(k_repack, dim3(P.nfronts, nbc), dim3(256), 0, g_stream, P, B, b0);
+  launch_check();
+}
+
 // ------------------------------------------------------------------ fused interior solve
 // One workgroup per subdomain, level-synchronous: all fronts of one tree level are processed
 // together, one work item per row of [pivot | update rows] (forward) or per pivot row (backward),
@@ -1219,6 +1242,19 @@ void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, c
 // is read with consecutive rows on consecutive lanes; with few items the k range is split over
 // 2 or 4 thread groups so that small levels still keep many loads in flight.
 struct FusedFront { int32_t c0, w, ri, c_off, a_off, lf_off, idx_off, pad; int64_t lp_off, q_off; };
+// addressing of one row of the L-side / U-side panel of a front (plain or packed, device.hpp):
+// L-side entry (r, k) = p[c1 k - tri k (k + 3) / 2], U11^{-1} entry (i, k) = p[c1 k + tri k (k + 1) / 2]
+__device__ inline const double* lside(const double* base, int packed, int r, int w, int ri, int& c1, int& tri) {
+  if (!packed) { c1 = w + ri; tri = 0; return base + r; }
+  if (r < w) { c1 = w; tri = 1; return base + (r - 1); }        // k (2w - k - 1) / 2 + r - k - 1 = (r - 1) + w k - k (k + 3) / 2
+  c1 = ri; tri = 0;
+  return base + ((w * (w - 1)) >> 1) + (r - w);
+}
+__device__ inline const double* uside(const double* base, int packed, int i, int w, int ri, int& c1, int& tri) {
+  if (!packed) { c1 = w + ri; tri = 0; return base + i; }
+  c1 = 0; tri = 1;
+  return base + ((w * (w - 1)) >> 1) + ri * w + i;
+}
 template <bool PROF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
                                                          double* __restrict__ x, long long* __restrict__ prof) {
@@ -1265,8 +1301,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int item = P.fw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
-        const int64_t ld = F.w + F.ri;
-        const double* __restrict__ p = fac + F.lp_off + r;
+        // entry (r, k) of the L-side panel sits at p[c1 * k - tri * k (k + 3) / 2]: plain columns (tri = 0), or the
+        // packed strictly-lower triangle for a pivot row of a packed panel (tri = 1)
+        int c1, tri;
+        const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
         double a[4];
@@ -1276,11 +1314,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         for (; k + 3 < kmax; k += 4) {
           double l[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) l[u] = p[ld * (k + u)];
+          for (int u = 0; u < 4; u++) l[u] = p[c1 * (k + u) - tri * (((k + u) * (k + u + 3)) >> 1)];
 #pragma unroll
           for (int u = 0; u < 4; u++) a[u] += l[u] * f[k + u];
         }
-        for (; k < kmax; k++) a[0] += p[ld * k] * f[k];
+        for (; k < kmax; k++) a[0] += p[c1 * k - tri * ((k * (k + 3)) >> 1)] * f[k];
         const double sum = (a[0] + a[1]) + (a[2] + a[3]);
         if (r < w) X[F.c0 + r] = f[r] + sum; else C[F.c_off + r - w] -= sum;
       }
@@ -1292,16 +1330,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int item = P.fw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
-        const int64_t ld = F.w + F.ri;
-        const double* __restrict__ p = fac + F.lp_off + r;
+        int c1, tri;
+        const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
+        auto at = [&](int kk) { return p[c1 * kk - tri * ((kk * (kk + 3)) >> 1)]; };
         int k = kg;
         for (; k + 3 * KG < kmax; k += 4 * KG) {
-          const double l0 = p[ld * k], l1 = p[ld * (k + KG)], l2 = p[ld * (k + 2 * KG)], l3 = p[ld * (k + 3 * KG)];
+          const double l0 = at(k), l1 = at(k + KG), l2 = at(k + 2 * KG), l3 = at(k + 3 * KG);
           a0 += l0 * f[k]; a1 += l1 * f[k + KG]; a2 += l2 * f[k + 2 * KG]; a3 += l3 * f[k + 3 * KG];
         }
-        for (; k < kmax; k += KG) a0 += p[ld * k] * f[k];
+        for (; k < kmax; k += KG) a0 += at(k) * f[k];
       }
       R[kg * RT + it] = (a0 + a1) + (a2 + a3);
       __syncthreads();
@@ -1325,8 +1364,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int item = P.bw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
-        const int64_t ld = w + ri;
-        const double* __restrict__ p = fac + F.lp_off + i;
+        // entry (i, k), k >= i, of U11^{-1}: column k of the tall panel, or of the packed upper triangle
+        int c1, tri;
+        const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
         const double* Xs = X + F.c0;
         double a[4];
 #pragma unroll
@@ -1335,11 +1375,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         for (; k + 3 < w; k += 4) {
           double l[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) l[u] = p[ld * (k + u)];
+          for (int u = 0; u < 4; u++) l[u] = p[c1 * (k + u) + tri * (((k + u) * (k + u + 1)) >> 1)];
 #pragma unroll
           for (int u = 0; u < 4; u++) a[u] += l[u] * Xs[k + u];
         }
-        for (; k < w; k++) a[0] += p[ld * k] * Xs[k];
+        for (; k < w; k++) a[0] += p[c1 * k + tri * ((k * (k + 1)) >> 1)] * Xs[k];
         const double* __restrict__ qv = fac + F.q_off + i;
         const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
         k = 0;
@@ -1366,15 +1406,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int item = P.bw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
-        const int64_t ld = w + ri;
-        const double* __restrict__ p = fac + F.lp_off + i;
+        int c1, tri;
+        const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
         const double* Xs = X + F.c0;
+        auto at = [&](int kk) { return p[c1 * kk + tri * ((kk * (kk + 1)) >> 1)]; };
         int k = i + kg;
         for (; k + 3 * KG < w; k += 4 * KG) {
-          const double l0 = p[ld * k], l1 = p[ld * (k + KG)], l2 = p[ld * (k + 2 * KG)], l3 = p[ld * (k + 3 * KG)];
+          const double l0 = at(k), l1 = at(k + KG), l2 = at(k + 2 * KG), l3 = at(k + 3 * KG);
           a0 += l0 * Xs[k]; a1 += l1 * Xs[k + KG]; a2 += l2 * Xs[k + 2 * KG]; a3 += l3 * Xs[k + 3 * KG];
         }
-        for (; k < w; k += KG) a0 += p[ld * k] * Xs[k];
+        for (; k < w; k += KG) a0 += at(k) * Xs[k];
         const double* __restrict__ qv = fac + F.q_off + i;
         const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
         k = kg;

@@ -111,6 +111,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   dplan.s_ent_begin = plan.s_ent_begin; dplan.s_ent_end = nent;
   dplan.scratch_size = plan.scratch_size; dplan.factor_size = plan.factor_size;
   dplan.contrib_size = plan.contrib_size;
+  dplan.packed = packed ? 1 : 0;
   {
     int32_t msr = 1;  // LDS vector of the one-workgroup-per-front solve kernels: small fronts only
     for (auto& F : plan.fronts) if (!F.big) msr = std::max(msr, F.w + F.ri);
@@ -174,6 +175,10 @@ void BatchedLU::factor_chunk(const double* kval, int32_t b0, int32_t nbc) {
       dev::factor_big_front(dplan, batch, h_fronts[s], k.data(), (int32_t)k.size(), b0, nbc, kval);
     }
   }
+}
+
+void BatchedLU::repack_chunk(int32_t b0, int32_t nbc) {
+  if (packed) dev::repack_fronts(dplan, batch, b0, nbc);
 }
 
 void BatchedLU::solve(double* x) const {
@@ -993,7 +998,6 @@ void LevelSolver::build_schur_setup() {
     C.d_pick = dev::upload(C.pick);
     C.d_lgptr = dev::upload(C.lgptr);
     C.d_tvloc = dev::upload(C.tvloc);
-    C.lu.upload(SCRATCH_BUDGET, true);
   }
   // ---- tables of the fused interior solve (classes whose vectors fit in LDS)
   constexpr int32_t LDS_CAP = 12288;  // doubles (96 KiB)
@@ -1003,13 +1007,16 @@ void LevelSolver::build_schur_setup() {
   fused_lds_ = 0;
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
-    plans.push_back(C.lu.dplan);
     const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + std::max(C.lu.plan.max_level_rows, 384) +
                          (int32_t)(C.lu.plan.fronts.size() * 6 + 1);   // X | C | F (+ R inside) | compact front descriptors (48 B)
     bool any_big = false;
     for (auto& L : C.lu.plan.big_levels) any_big |= !L.empty();
-    if (any_big || C.lu.plan.max_level_rows > dev::FUSED_MAX_ITEMS || need > LDS_CAP || C.lu.plan.nI == 0 ||
-        C.lu.plan.fw_items.empty() || std::getenv("HYMLS_MI_NO_FUSED_SOLVE")) continue;
+    const bool fused = !(any_big || C.lu.plan.max_level_rows > dev::FUSED_MAX_ITEMS || need > LDS_CAP || C.lu.plan.nI == 0 ||
+                         C.lu.plan.fw_items.empty() || std::getenv("HYMLS_MI_NO_FUSED_SOLVE"));
+    C.lu.packed = fused && !std::getenv("HYMLS_MI_NO_PACKED_PANELS");
+    C.lu.upload(SCRATCH_BUDGET, true);
+    plans.push_back(C.lu.dplan);
+    if (!fused) continue;
     cls_fused_[c] = 1;
     fused_lds_ = std::max(fused_lds_, need);
     for (size_t b = 0; b < C.lu.members.size(); b++)
@@ -1203,6 +1210,7 @@ void LevelSolver::compute() {
     for (int b0 = 0; b0 < nb; b0 += C.lu.chunk) {
       const int nbc = std::min(C.lu.chunk, nb - b0);
       C.lu.factor_chunk(d_kval_, b0, nbc);
+      C.lu.repack_chunk(b0, nbc);
       if (C.pat.nS == 0) continue;
       if (!direct_schur_)
         dev::sblock_transform(C.pat.nS, C.ngl, C.d_lgptr, C.d_tvloc + (size_t)b0 * C.pat.nS, C.lu.batch.sblock, nbc);

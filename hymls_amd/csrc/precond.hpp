@@ -37,10 +37,12 @@ struct BatchedLU {
   std::vector<void*> owned;       // device allocations to free
   int32_t nent = 0;
   int32_t chunk = 0;              // members factored per pass
+  bool packed = false;            // panels repacked after the factorisation (classes solved by the fused kernel)
   ~BatchedLU();
   void upload(int64_t scratch_budget_doubles, bool with_sblock);
   // numeric factorisation of members [b0,b0+nbc) (scratch slots 0..nbc-1)
   void factor_chunk(const double* kval, int32_t b0, int32_t nbc);
+  void repack_chunk(int32_t b0, int32_t nbc);   // after factor_chunk and after the separator block was read
   void solve(double* x) const;    // forward + backward, all members, in place
   int32_t check_flag() const;
 };

@@ -255,6 +255,24 @@ void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, c
   for (auto& wv : writes) *wv.first = wv.second;
 }
 
+void repack_fronts(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc) {
+  std::vector<double> tmp;
+  for (int b = b0; b < b0 + nbc; b++)
+    for (int s = 0; s < P.nfronts; s++) {
+      const FrontD& F = P.fronts[s];
+      const int64_t w = F.w, ri = F.ri, ld = w + ri;
+      double* Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off;
+      tmp.assign(Lp, Lp + ld * w);
+      for (int64_t k = 0; k < w; k++)
+        for (int64_t i = 0; i < ld; i++) {
+          const double v = tmp[i + ld * k];
+          if (i >= w) Lp[packed_l21(w, ri, i - w, k)] = v;
+          else if (i > k) Lp[packed_lower(w, i, k)] = v;
+          else Lp[packed_upper(w, ri, i, k)] = v;
+        }
+    }
+}
+
 void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t, double* x) {
   // level-synchronous walk with the same work-item tables the HIP kernel uses
   std::vector<double> C, Fv, out;
@@ -278,7 +296,10 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
         const double* Lp = fac + F.lp_off;
         const int kmax = r < w ? r : w;
         double a = 0;
-        for (int k = 0; k < kmax; k++) a += Lp[r + (int64_t)ld * k] * Fv[F.lf_off + k];
+        for (int k = 0; k < kmax; k++) {
+          const double l = !P.packed ? Lp[r + (int64_t)ld * k] : (r < w ? Lp[packed_lower(w, r, k)] : Lp[packed_l21(w, F.ri, r - w, k)]);
+          a += l * Fv[F.lf_off + k];
+        }
         if (r < w) X[F.c0 + r] = Fv[F.lf_off + r] + a; else C[F.c_off + r - w] -= a;
       }
     }
@@ -290,7 +311,7 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
         const double* Lp = fac + F.lp_off;
         const double* Q = fac + F.q_off;
         double a = 0;
-        for (int k = i; k < w; k++) a += Lp[i + (int64_t)ld * k] * X[F.c0 + k];
+        for (int k = i; k < w; k++) a += (P.packed ? Lp[packed_upper(w, ri, i, k)] : Lp[i + (int64_t)ld * k]) * X[F.c0 + k];
         for (int k = 0; k < ri; k++) a -= Q[i + (int64_t)w * k] * X[P.fidx[F.idx_off + w + k]];
         out[it - P.bw_ptr[lev]] = a;
       }

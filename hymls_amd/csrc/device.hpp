@@ -45,6 +45,10 @@ struct FrontD {
   int64_t f_off, lp_off, q_off;
 };
 
+// forward work item of the fused solve with its assembly sources inline: one 16-byte load replaces the chain
+// item -> asm_ptr -> asm_src (n == 0xffff: more than 5 sources, use the lists)
+struct alignas(16) FwRec { int32_t item; uint16_t n; uint16_t s[5]; };
+
 struct PlanD {
   int32_t nI, nS, nfronts, nent;   // nent: entries of the extended local CSR
   const FrontD* fronts;
@@ -59,6 +63,7 @@ struct PlanD {
   int32_t asm_rows;
   const int32_t* fw_ptr;    // [nlev + 1] level-synchronous fused solve: forward work items
   const int32_t* fw_items;  // front << 16 | row
+  const struct FwRec* fw_rec;   // per forward item: the item and its (few) assembly sources inline
   const int32_t* bw_ptr;
   const int32_t* bw_items;
   int32_t nlev, max_level_rows;

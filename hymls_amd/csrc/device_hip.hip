@@ -1287,11 +1287,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   for (int lev = 0; lev < P.nlev; lev++) {
     const int ib = P.fw_ptr[lev], ni = P.fw_ptr[lev + 1] - ib;
     for (int it = tid; it < ni; it += 256) {
-      const int item = P.fw_items[ib + it];
+      const FwRec rc = P.fw_rec[ib + it];                // item + inline assembly sources: one round trip
+      const int item = rc.item;
       const FusedFront& F = LF[item >> 16];
       const int r = item & 0xffff;
       double v = r < F.w ? X[F.c0 + r] : 0.0;
-      for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) v += C[P.asm_src[t]];
+      if (rc.n != 0xffff) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) if (q < rc.n) v += C[rc.s[q]];
+      } else {
+        for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) v += C[P.asm_src[t]];
+      }
       if (r < F.w) Fv[F.lf_off + r] = v; else C[F.c_off + r - F.w] = v;   // update rows are assembled in place
     }
     __syncthreads();

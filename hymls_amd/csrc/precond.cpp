@@ -107,6 +107,20 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   dplan.asm_rows = plan.asm_rows;
   dplan.fw_ptr = keep(dev::upload(plan.fw_ptr)); dplan.fw_items = keep(dev::upload(plan.fw_items));
   dplan.bw_ptr = keep(dev::upload(plan.bw_ptr)); dplan.bw_items = keep(dev::upload(plan.bw_items));
+  {
+    std::vector<dev::FwRec> rec(plan.fw_items.size());
+    for (size_t t = 0; t < rec.size(); t++) {
+      const int32_t item = plan.fw_items[t];
+      const Front& F = plan.fronts[item >> 16];
+      const int32_t a = F.a_off + (item & 0xffff);
+      const int32_t nb = plan.asm_ptr[a], ne = plan.asm_ptr[a + 1];
+      dev::FwRec r{item, (uint16_t)(ne - nb), {0, 0, 0, 0, 0}};
+      if (ne - nb > 5 || plan.contrib_size > 65535) r.n = 0xffff;
+      else for (int32_t q = nb; q < ne; q++) r.s[q - nb] = (uint16_t)plan.asm_src[q];
+      rec[t] = r;
+    }
+    dplan.fw_rec = keep(dev::upload(rec));
+  }
   dplan.nlev = (int32_t)plan.levels.size(); dplan.max_level_rows = plan.max_level_rows;
   dplan.s_ent_begin = plan.s_ent_begin; dplan.s_ent_end = nent;
   dplan.scratch_size = plan.scratch_size; dplan.factor_size = plan.factor_size;

@@ -190,5 +190,9 @@ void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag);
 void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* ids,
                   const double* x, double* y);
 
+// all separator blocks of a level in one launch (blocks of any order; heavy ones first)
+struct BlkD { const double* binv; const int32_t* ids; int32_t nb, pad; };
+void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, double* y);
+
 }  // namespace dev
 }  // namespace hymls

@@ -1637,6 +1637,36 @@ __global__ void __launch_bounds__(256) k_blocks_apply(int32_t nb, const double* 
     y[id[i]] = s0 + s1;
   }
 }
+// one wave per block, lane = row, eight columns in flight
+__global__ void __launch_bounds__(64) k_blocks_apply_all(const BlkD* __restrict__ blocks, const double* __restrict__ x, double* __restrict__ y) {
+  extern __shared__ double xs[];
+  const BlkD D = blocks[blockIdx.x];
+  const int nb = D.nb;
+  for (int j = threadIdx.x; j < nb; j += 64) xs[j] = x[D.ids[j]];
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += 64) {
+    const double* __restrict__ M = D.binv + i;
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = 0.0;
+    int j = 0;
+    for (; j + 7 < nb; j += 8) {
+      double l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) l[u] = M[(int64_t)nb * (j + u)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] += l[u] * xs[j + u];
+    }
+    for (; j < nb; j++) a[0] += M[(int64_t)nb * j] * xs[j];
+    y[D.ids[i]] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+}
+void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, double* y) {
+  if (nblk <= 0) return;
+  hipLaunchKernelGGL(k_blocks_apply_all, dim3(nblk), dim3(64), (size_t)max_nb * sizeof(double), g_stream, blocks, x, y);
+  launch_check();
+}
+
 void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* ids, const double* x, double* y) {
   if (nb <= 0 || nblk <= 0) return;
   const int bs = nb <= 64 ? 64 : (nb <= 128 ? 128 : 256);

@@ -343,6 +343,7 @@ LevelSolver::~LevelSolver() {
                   d_nrhs_, d_nsol_};
   for (void* q : ptrs) dev::free(q);
   dev::free(d_fsubs_); dev::free(d_fplans_);
+  dev::free(d_blkd_);
   dev::free(d_lsubs_); dev::free(d_lfw_); dev::free(d_lbw_); dev::free(d_ytmp_);
   for (auto& b : blocks_) { dev::free(b.d_binv); dev::free(b.d_ids); dev::free(b.d_pull_ptr); dev::free(b.d_pull_base); }
 }
@@ -977,6 +978,19 @@ void LevelSolver::build_schur_setup() {
       B.d_pull_ptr = dev::upload(B.pull_ptr); B.d_pull_base = dev::upload(B.pull_base);
       B.d_binv = (double*)dev::alloc((size_t)B.nb * B.nb * B.nblk * sizeof(double));
     }
+    {
+      // one descriptor per block, largest first, for the single-launch apply
+      std::vector<dev::BlkD> bd;
+      blk_max_nb_ = 0;
+      for (auto& B : blocks_) {
+        for (int q = 0; q < B.nblk; q++)
+          bd.push_back(dev::BlkD{B.d_binv + (int64_t)q * B.nb * B.nb, B.d_ids + (int64_t)q * B.nb, B.nb, 0});
+        blk_max_nb_ = std::max(blk_max_nb_, B.nb);
+      }
+      std::stable_sort(bd.begin(), bd.end(), [](const dev::BlkD& a, const dev::BlkD& b) { return a.nb > b.nb; });
+      n_blk_ = (int32_t)bd.size();
+      d_blkd_ = dev::upload(bd);
+    }
     d_gptr_ = dev::upload(gptr_); d_otw_ = dev::upload(otw_); d_vs_ = dev::upload(vs_);
     d_vrhs_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
     d_vsol_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
@@ -1350,7 +1364,7 @@ void LevelSolver::schur_apply(double* rhs2, double* x2) {
   // SchurPreconditioner::ApplyInverse (reference src/HYMLS_SchurPreconditioner.cpp:1010-1093)
   const int ng = (int)vs_.size();
   dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);                       // B' = H rhs
-  for (auto& B : blocks_) dev::blocks_apply(B.nb, B.nblk, B.d_binv, B.d_ids, rhs2, x2);
+  dev::blocks_apply_all(n_blk_, d_blkd_, blk_max_nb_, rhs2, x2);
   dev::gather(ng, d_vs_, rhs2, d_vrhs_);
   if (profiling && level_ == 0) dev::mark(4, true);
   next_apply(d_vrhs_, d_vsol_);

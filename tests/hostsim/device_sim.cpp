@@ -404,5 +404,20 @@ void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* i
   }
 }
 
+void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t, const double* x, double* y) {
+  std::vector<double> xs, out;
+  for (int b = 0; b < nblk; b++) {
+    const BlkD& D = blocks[b];
+    xs.resize(D.nb); out.resize(D.nb);
+    for (int j = 0; j < D.nb; j++) xs[j] = x[D.ids[j]];
+    for (int i = 0; i < D.nb; i++) {
+      double s = 0;
+      for (int j = 0; j < D.nb; j++) s += D.binv[i + (int64_t)D.nb * j] * xs[j];
+      out[i] = s;
+    }
+    for (int i = 0; i < D.nb; i++) y[D.ids[i]] = out[i];
+  }
+}
+
 }  // namespace dev
 }  // namespace hymls

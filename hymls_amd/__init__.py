@@ -10,5 +10,7 @@ HIP library is missing, importing :class:`Preconditioner` users get a loud error
 from .api import (Preconditioner, HymlsError, load_library, generate_matrix, generate_testvector, generate_rows,
                   generate_testvector_rows, LIB_PATH)
 
-__all__ = ["Preconditioner", "HymlsError", "load_library", "generate_matrix", "generate_testvector", "generate_rows",
+from .solver import Solver
+
+__all__ = ["Solver", "Preconditioner", "HymlsError", "load_library", "generate_matrix", "generate_testvector", "generate_rows",
            "generate_testvector_rows", "LIB_PATH"]

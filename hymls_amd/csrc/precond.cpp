@@ -344,6 +344,7 @@ LevelSolver::~LevelSolver() {
   for (void* q : ptrs) dev::free(q);
   dev::free(d_fsubs_); dev::free(d_fplans_);
   dev::free(d_blkd_);
+  dev::free(d_mv_row_); dev::free(d_mv_col_); dev::free(d_mv_src_); dev::free(d_mv_node_); dev::free(d_mv_val_); dev::free(d_mv_x_);
   dev::free(d_lsubs_); dev::free(d_lfw_); dev::free(d_lbw_); dev::free(d_ytmp_);
   for (auto& b : blocks_) { dev::free(b.d_binv); dev::free(b.d_ids); dev::free(b.d_pull_ptr); dev::free(b.d_pull_base); }
 }
@@ -1227,6 +1228,7 @@ void LevelSolver::compute() {
     t0 = wall();
   };
   dev::h2d(d_kval_, K_.val.data(), K_.val.size() * sizeof(double));
+  mv_stale_ = true;
   dev::gather((int64_t)a12_col_.size(), d_a12_src_, d_kval_, d_a12_val_);
   dev::gather((int64_t)a21_col_.size(), d_a21_src_, d_kval_, d_a21_val_);
   // ---- interior factorisations + separator blocks, class by class, chunk by chunk
@@ -1400,9 +1402,65 @@ void LevelSolver::apply_inverse(const double* b, double* x) {
   if (profiling) dev::mark(0, false);
 }
 
-void LevelSolver::matvec(const double* x, double* y) const {
-  HYMLS_CHECK(!comm_->distributed(), -99, "matvec of the sharded operator belongs to the caller (halo exchange of K)");
-  dev::spmv(K_.n, d_krow_, d_kcol_, d_kval_, x, y, 1.0, 0.0);
+// plan of the sharded K x: which columns of my owned rows live elsewhere, and who owns them.  The owners are found by
+// publishing the wanted gids to everybody (boundary layers only) and letting every rank claim what it owns.
+void LevelSolver::build_matvec() {
+  const int n = K_.n, nown = (int)owned_gids_.size();
+  ivec user(n, -1);
+  {
+    int u = 0;
+    for (int i = 0; i < nrows_; i++) if (intidx_[i] >= 0 || (pos2_[i] >= 0 && pos2_[i] < n2_)) user[i] = u++;
+  }
+  ivec row(1, 0), col, src, node(nown);
+  std::vector<char> wanted(n, 0);
+  ivec want;
+  for (int i = 0; i < nrows_; i++) {
+    if (user[i] < 0) continue;
+    node[user[i]] = i;
+    for (int e = K_.rowptr[i]; e < K_.rowptr[i + 1]; e++) {
+      const int c = K_.col[e];
+      col.push_back(c); src.push_back(e);
+      if (user[c] < 0 && !wanted[c]) { wanted[c] = 1; want.push_back(gids_[c]); }
+    }
+    row.push_back((int32_t)col.size());
+  }
+  // (rows were visited in local order = user order)
+  std::vector<int64_t> cnt;
+  ivec all = comm_->allgather(want, &cnt);
+  std::vector<ivec> claim(comm_->size);
+  {
+    int64_t off = 0;
+    for (int q = 0; q < comm_->size; q++) {
+      for (int64_t t = off; t < off + cnt[q]; t++) {
+        const int l = g2l_[all[t]];
+        if (q != comm_->rank && l >= 0 && user[l] >= 0) claim[q].push_back(all[t]);
+      }
+      off += cnt[q];
+    }
+  }
+  auto offered = comm_->exchange_lists(claim);   // offered[q]: the gids of my list that rank q owns
+  std::vector<std::vector<int64_t>> keys(comm_->size);
+  std::vector<ivec> dst(comm_->size);
+  int64_t found = 0;
+  for (int q = 0; q < comm_->size; q++)
+    for (int32_t g : offered[q]) { keys[q].push_back(g); dst[q].push_back(g2l_[g]); found++; }
+  HYMLS_CHECK(found == (int64_t)want.size(), -3, "sharded matvec: a column of an owned row has no (or more than one) owner");
+  xch_mv_.build(*comm_, keys, dst, [&](int64_t g) { const int l = g2l_[g]; return l >= 0 ? user[l] : -1; });
+  d_mv_row_ = dev::upload(row); d_mv_col_ = dev::upload(col); d_mv_src_ = dev::upload(src); d_mv_node_ = dev::upload(node);
+  mv_nnz_ = (int64_t)col.size();
+  d_mv_val_ = (double*)dev::alloc(std::max<size_t>(1, col.size()) * sizeof(double));
+  d_mv_x_ = (double*)dev::alloc((size_t)std::max(n, 1) * sizeof(double));
+  mv_ready_ = true;
+}
+
+void LevelSolver::matvec(const double* x, double* y) {
+  if (!comm_->distributed()) { dev::spmv(K_.n, d_krow_, d_kcol_, d_kval_, x, y, 1.0, 0.0); return; }
+  if (!mv_ready_) build_matvec();
+  if (mv_stale_) { dev::gather(mv_nnz_, d_mv_src_, d_kval_, d_mv_val_); mv_stale_ = false; }   // new values since the last Compute
+  const int nown = (int)owned_gids_.size();
+  dev::scatter(nown, d_mv_node_, x, d_mv_x_);                    // owned entries to their local nodes
+  xch_mv_.forward(x, d_mv_x_);                                   // columns owned elsewhere
+  dev::spmv(nown, d_mv_row_, d_mv_col_, d_mv_val_, d_mv_x_, y, 1.0, 0.0);
 }
 
 void LevelSolver::add_stats(ApplyStats& st, bool as_coarse) const {

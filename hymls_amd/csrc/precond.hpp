@@ -98,7 +98,9 @@ class LevelSolver : public Operator {
   void apply_inverse(const double* b, double* x) override;
   int64_t size() const override { return global_n_; }
   void add_stats(ApplyStats& st, bool as_coarse) const override;
-  void matvec(const double* x, double* y) const;  // y = K x (level ordering, one rank only)
+  // y = K x on the rows this rank owns (vectors in the layout of apply_inverse); sharded: collective, the values
+  // of the columns owned elsewhere are imported first (the Epetra_CrsMatrix::Apply of the reference's Krylov loop)
+  void matvec(const double* x, double* y);
 
   // introspection
   const HierMap& hiermap() const { return hm_; }
@@ -154,7 +156,13 @@ class LevelSolver : public Operator {
   ivec sd_center_;             // 3 ints per subdomain (mean coordinate of its separator nodes)
   std::vector<std::unique_ptr<Cls>> cls_;
   // halo exchanges of the apply (empty on one rank)
-  Exchange xch_int_, xch_sep_, xch_down_;
+  Exchange xch_int_, xch_sep_, xch_down_, xch_mv_;
+  // sharded K x: owned rows in user order over the local nodes, built on first use
+  bool mv_ready_ = false, mv_stale_ = true;
+  int32_t *d_mv_row_ = nullptr, *d_mv_col_ = nullptr, *d_mv_src_ = nullptr, *d_mv_node_ = nullptr;
+  double *d_mv_val_ = nullptr, *d_mv_x_ = nullptr;
+  int64_t mv_nnz_ = 0;
+  void build_matvec();
   // records of neighbouring ranks' subdomains that touch separators owned here
   struct RecSeg { int64_t off, len; };
   std::vector<RecSeg> rec_send_;              // in send order (peer-major)

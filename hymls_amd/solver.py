@@ -9,10 +9,13 @@ Parameter names are the reference's ("Solver" sublist of the XML files, e.g. tes
      "Left or Right Preconditioning": "Right" | "Left",
      "Iterative Solver": {"Convergence Tolerance": 1e-8, "Maximum Iterations": 500,
                           "Num Blocks": 250, "Maximum Restarts": 20}}
-One GPU only: the sharded K x product of a multi-rank Krylov loop is the caller's.
+Sharded runs (the operator and the preconditioner are sharded hymls_amd.Preconditioner objects): every rank
+calls the solver with its part of B; inner products are all-reduced over torch.distributed, K x imports the
+columns owned by other ranks (hymls_mi_matvec), ApplyInverse exchanges as described in DESIGN.md section 6.
 """
 import numpy as np
 import torch
+import torch.distributed as dist
 
 
 class Solver:
@@ -43,6 +46,22 @@ class Solver:
 
     def SetOperator(self, K):
         self._matvec = K.MatVec if hasattr(K, "MatVec") else K
+        self._sharded = getattr(K, "_comm", None) is not None
+
+    # --- reductions (all-reduced over the ranks of a sharded run)
+    def _reduce(self, t):
+        if self._sharded:
+            dist.all_reduce(t)
+        return t
+
+    def _dot(self, a, b):
+        return float(self._reduce(torch.dot(a, b).reshape(1)))
+
+    def _norm(self, a):
+        return float(np.sqrt(self._dot(a, a)))
+
+    def _nonzero(self, x):
+        return self._dot(x, x) > 0.0
 
     def SetPrecond(self, P):
         self._prec = (P.ApplyInverse if hasattr(P, "ApplyInverse") else P)
@@ -89,10 +108,10 @@ class Solver:
         x = x0
         its, rel, beta0 = 0, float("inf"), None
         for _cycle in range(self.max_restarts + 1):
-            r = b - self.ApplyMatrix(x) if (its > 0 or bool(x.any())) else b.clone()
+            r = b - self.ApplyMatrix(x) if (its > 0 or self._nonzero(x)) else b.clone()
             if not right:
                 r = self.ApplyPrec(r)
-            beta = float(r.norm())
+            beta = self._norm(r)
             if beta0 is None:
                 beta0 = beta
             if beta0 == 0.0:
@@ -108,10 +127,10 @@ class Solver:
             for k in range(m):
                 w = self.ApplyMatrix(self.ApplyPrec(V[k])) if right else self.ApplyPrec(self.ApplyMatrix(V[k]))
                 Vk = V[:k + 1]
-                h = torch.mv(Vk, w); w -= torch.mv(Vk.t(), h)
-                h2 = torch.mv(Vk, w); w -= torch.mv(Vk.t(), h2)
+                h = self._reduce(torch.mv(Vk, w)); w -= torch.mv(Vk.t(), h)
+                h2 = self._reduce(torch.mv(Vk, w)); w -= torch.mv(Vk.t(), h2)
                 H[:k + 1, k] = (h + h2).cpu().numpy()
-                H[k + 1, k] = float(w.norm())
+                H[k + 1, k] = self._norm(w)
                 if H[k + 1, k] > 0:
                     V[k + 1] = w / H[k + 1, k]
                 for i in range(k):
@@ -136,25 +155,25 @@ class Solver:
     # --- preconditioned CG (Belos PseudoBlockCG semantics: relative to the initial residual)
     def _cg(self, b, x0):
         x = x0.clone()
-        r = b - self.ApplyMatrix(x) if bool(x.any()) else b.clone()
+        r = b - self.ApplyMatrix(x) if self._nonzero(x) else b.clone()
         z = self.ApplyPrec(r)
         p = z.clone()
-        rz = float(torch.dot(r, z))
-        r0 = float(r.norm())
+        rz = self._dot(r, z)
+        r0 = self._norm(r)
         if r0 == 0.0:
             return x, 0, 0.0
         its, rel = 0, 1.0
         while its < self.maxit:
             Ap = self.ApplyMatrix(p)
-            alpha = rz / float(torch.dot(p, Ap))
+            alpha = rz / self._dot(p, Ap)
             x += alpha * p
             r -= alpha * Ap
             its += 1
-            rel = float(r.norm()) / r0
+            rel = self._norm(r) / r0
             if rel <= self.tol:
                 break
             z = self.ApplyPrec(r)
-            rz_new = float(torch.dot(r, z))
+            rz_new = self._dot(r, z)
             p = z + (rz_new / rz) * p
             rz = rz_new
         return x, its, rel

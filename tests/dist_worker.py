@@ -62,26 +62,52 @@ def main():
     P.SetMatrixRows(req, rows)                 # SetMatrix with the same pattern + Compute again
     P.Compute()
     x_loc3 = P.ApplyInverse(b[owned])
+    # sharded K x and the sharded Krylov loop (hostsim runs: CPU tensors)
+    kx = P.MatVec(b[owned])
+    its_sh, xs_loc = -1, None
+    if mode == "hostsim":
+        meth = "CG" if eq == "Laplace" else "GMRES"
+        S = hymls_amd.Solver(P, P, {"Krylov Method": meth, "Iterative Solver": {"Convergence Tolerance": 1e-8, "Maximum Iterations": 300, "Num Blocks": 300}})
+        x_ex = np.random.default_rng(9).uniform(-1, 1, N)          # consistent right-hand side b = K x_ex
+        rhs_loc = P.MatVec(x_ex[owned])
+        xs_loc = S.ApplyInverse(torch.from_numpy(rhs_loc.copy())).numpy()
+        its_sh = S.getNumIter()
     parts = [None] * world
-    dist.all_gather_object(parts, (owned, x_loc, float(np.abs(x_loc2 - x_loc).max()), float(np.abs(x_loc3 - x_loc).max())))
+    dist.all_gather_object(parts, (owned, x_loc, float(np.abs(x_loc2 - x_loc).max()), float(np.abs(x_loc3 - x_loc).max()), kx, xs_loc))
     ok = True
     if rank == 0:
         x = np.full(N, np.nan)
         cover = np.zeros(N, np.int64)
-        for o, xl, _, _ in parts:
+        kxg = np.zeros(N); xsg = np.zeros(N)
+        for o, xl, _, _, kxl, xsl in parts:
             x[o] = xl
             cover[o] += 1
+            kxg[o] = kxl
+            if xsl is not None:
+                xsg[o] = xsl
         K = hymls_amd.generate_matrix(eq, nx, ny, nz, a=a, lib=lib)
         tv = hymls_amd.generate_testvector(*K, lib=lib)
         P0 = hymls_amd.Preconditioner(K, prm, testVector=tv, lib=lib)
         P0.Compute()
         x0 = P0.ApplyInverse(b)
         err = float(np.linalg.norm(x - x0) / np.linalg.norm(x0))
-        res = {"world": world, "cover_ok": bool((cover == 1).all()), "rel_err": err,
+        import scipy.sparse as sp
+        Ks = sp.csr_matrix((K[2], K[1], K[0]), shape=(N, N))
+        mv_err = float(np.linalg.norm(kxg - Ks @ b) / np.linalg.norm(Ks @ b))
+        its_one, sol_res = -1, 0.0
+        if its_sh >= 0:
+            S0 = hymls_amd.Solver(P0, P0, {"Krylov Method": meth, "Iterative Solver": {"Convergence Tolerance": 1e-8, "Maximum Iterations": 300, "Num Blocks": 300}})
+            rhs = Ks @ np.random.default_rng(9).uniform(-1, 1, N)
+            S0.ApplyInverse(torch.from_numpy(rhs.copy()))
+            its_one = S0.getNumIter()
+            sol_res = float(np.linalg.norm(rhs - Ks @ xsg) / np.linalg.norm(rhs))
+        res = {"world": world, "cover_ok": bool((cover == 1).all()), "rel_err": err, "matvec_err": mv_err,
+               "krylov_its_sharded": its_sh, "krylov_its_one_rank": its_one, "krylov_residual": sol_res,
                "repeat_diff": max(p[2] for p in parts), "recompute_diff": max(p[3] for p in parts),
                "levels": P0.level_sizes(), "levels_sharded": P.level_sizes()}
         print("DIST_RESULT " + json.dumps(res), flush=True)
-        ok = res["cover_ok"] and err < 1e-9 and res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12
+        ok = (res["cover_ok"] and err < 1e-9 and res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12 and mv_err < 1e-13
+              and abs(its_sh - its_one) <= 1 and sol_res < 1e-6)
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

@@ -42,6 +42,8 @@ def test_sharded_matches_one_rank(hostsim_lib, world, eq, nx, ny, nz, sx, levels
     assert res["levels"] == res["levels_sharded"]
     assert res["rel_err"] < 1e-12
     assert res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12
+    assert res["matvec_err"] < 1e-13                                        # sharded K x with imported columns
+    assert abs(res["krylov_its_sharded"] - res["krylov_its_one_rank"]) <= 1 and res["krylov_residual"] < 1e-6
 
 
 @pytest.mark.parametrize("world,eq,nx,ny,nz,sx,levels,cx,part", [

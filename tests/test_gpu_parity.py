@@ -288,3 +288,11 @@ def test_sharded_transport_over_rccl_single_rank(gpu_lib):
                      env_extra={"HYMLS_MI_FORCE_SHARDED": "1"})
     assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
     assert res["rel_err"] < 1e-10 and res["repeat_diff"] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("re,part,levels,its_max", [("re1000", "Cartesian", 1, 100), ("re1000", "Skew Cartesian", 1, 110), ("re1000", "Cartesian", 2, 120)])
+def test_reference_driven_cavity_2d_gpu(gpu_lib, re, part, levels, its_max):
+    """the reference's 2D driven-cavity Jacobian at Re 1000 (its own test data) on the GPU path"""
+    from test_hostsim_parity import cavity2d_case
+    cavity2d_case(gpu_lib, re, part, levels, its_max)

@@ -160,3 +160,45 @@ def test_darcy3d_saddle_point(hostsim_lib, levels):
     O = oracle_prec(A, tv, "Stokes-C", n, 8, levels, partitioner="Skew Cartesian")
     b = np.random.default_rng(22).uniform(-1, 1, A.shape[0])
     assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-8
+
+
+def _cavity2d(re):
+    """the reference's own 2D driven-cavity linear system (testSuite/data/DrivenCavity/32x32/<re>, input of
+    testSuite/cavity.xml), committed as a fixture by tests/golden/make_golden.py"""
+    import os
+    import scipy.sparse as sp
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "drivencavity32_2d_%s.npz" % re))
+    A = sp.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=(3072, 3072))
+    return A, z["rhs"], z["sol"]
+
+
+def cavity2d_case(lib, re, part, levels, its_max):
+    from oracle import galeri, krylov
+    A, rhs, sol = _cavity2d(re)
+    assert np.linalg.norm(A @ sol - rhs) <= 1e-12 * np.linalg.norm(rhs)          # the fixture is consistent
+    tv = galeri.create_testvector(A)
+    prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 2, "nx": 32, "ny": 32, "nz": 1},
+           "Preconditioner": {"Separator Length": 4, "Number of Levels": levels, "Partitioner": part}}
+    P = product_prec(A, tv, prm, lib)
+    O = OraclePrec2D(A, tv, part, levels)
+    b = np.random.default_rng(31).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-9
+    x, its, res = krylov.gmres(lambda v: A @ v, rhs, P.ApplyInverse, tol=1e-8, maxit=250)
+    _, its_o, _ = krylov.gmres(lambda v: A @ v, rhs, O.apply_inverse, tol=1e-8, maxit=250)
+    assert abs(its - its_o) <= 1 and its <= its_max
+    vel = np.arange(A.shape[0]) % 3 != 2                                             # pressure is defined up to a constant
+    assert np.linalg.norm((x - sol)[vel]) <= 1e-6 * np.linalg.norm(sol[vel])
+
+
+def OraclePrec2D(A, tv, part, levels):
+    from oracle.hymls import Preconditioner as OraclePrec
+    p = Params(nx=32, ny=32, nz=1, sx=4, levels=levels, equations="Stokes-C", dim=2, partitioner=part).finalize()
+    return OraclePrec(A, p, testvector=tv).compute()
+
+
+@pytest.mark.parametrize("re,part,levels,its_max", [
+    ("re0", "Cartesian", 1, 60), ("re1000", "Cartesian", 1, 100), ("re1000", "Skew Cartesian", 1, 110), ("re1000", "Cartesian", 2, 120)])
+def test_reference_driven_cavity_2d(hostsim_lib, re, part, levels, its_max):
+    """2D Navier-Stokes Jacobians of the reference's test data (nonsymmetric at Re 1000), solved to the
+    reference's stored solution; same GMRES iteration count as the oracle."""
+    cavity2d_case(hostsim_lib, re, part, levels, its_max)

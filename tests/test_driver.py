@@ -1,0 +1,93 @@
+"""hymls_amd.driver: the reference's driver flow (Teuchos XML parameter files, MatrixMarket linear systems) on
+the reference's own cavity.xml shape and data (2D driven cavity 32x32, committed as a fixture)."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+XML = """<ParameterList name="Trilinos HYMLS">
+  <ParameterList name="Driver">
+    <Parameter name="Number of factorizations" type="int" value="1"/>
+    <Parameter name="Number of solves" type="int" value="1"/>
+    <Parameter name="Read Linear System" type="bool" value="1"/>
+    <Parameter name="Data Directory" type="string" value="%s"/>
+    <Parameter name="File Format" type="string" value="MatrixMarket"/>
+    <Parameter name="RHS Available" type="bool" value="1"/>
+    <Parameter name="Exact Solution Available" type="bool" value="1"/>
+  </ParameterList>
+  <ParameterList name="Problem">
+    <Parameter name="Equations" type="string" value="Stokes-C"/>
+    <Parameter name="Dimension" type="int" value="2"/>
+    <Parameter name="nx" type="int" value="32"/>
+    <Parameter name="ny" type="int" value="32"/>
+    <Parameter name="nz" type="int" value="1"/>
+  </ParameterList>
+  <ParameterList name="Solver">
+    <Parameter name="Krylov Method" type="string" value="GMRES"/>
+    <ParameterList name="Iterative Solver">
+      <Parameter name="Maximum Iterations" type="int" value="250"/>
+      <Parameter name="Maximum Restarts" type="int" value="1"/>
+      <Parameter name="Convergence Tolerance" type="double" value="1.0e-10"/>
+    </ParameterList>
+  </ParameterList>
+  <ParameterList name="Preconditioner">
+    <Parameter name="Partitioner" type="string" value="Cartesian"/>
+    <Parameter name="Preconditioner Variant" type="string" value="Block Diagonal"/>
+    <Parameter name="Separator Length" type="int" value="4"/>
+    <Parameter name="Number of Levels" type="int" value="1"/>
+  </ParameterList>
+</ParameterList>
+"""
+
+OVERLAY = """<ParameterList name="Trilinos HYMLS">
+  <ParameterList name="Preconditioner">
+    <Parameter name="Number of Levels" type="int" value="2"/>
+  </ParameterList>
+</ParameterList>
+"""
+
+
+def _write_case(tmp_path, re):
+    z = np.load(os.path.join(HERE, "golden", "drivencavity32_2d_%s.npz" % re))
+    d = tmp_path / "data"
+    d.mkdir()
+    n = z["indptr"].size - 1
+    rows = np.repeat(np.arange(n), np.diff(z["indptr"]))
+    with open(d / "jac.mtx", "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%% test fixture\n%d %d %d\n" % (n, n, z["data"].size))
+        for r, c, v in zip(rows, z["indices"], z["data"]):
+            f.write("%d %d %.17g\n" % (r + 1, c + 1, v))
+    for name in ("rhs", "sol"):
+        with open(d / (name + ".mtx"), "w") as f:
+            f.write("%%%%MatrixMarket matrix array real general\n%d 1\n" % n)
+            f.write("\n".join("%.17g" % v for v in z[name]) + "\n")
+    xml = tmp_path / "cavity.xml"
+    xml.write_text(XML % str(d))
+    ov = tmp_path / "levels2.xml"
+    ov.write_text(OVERLAY)
+    return str(xml), str(ov)
+
+
+def check(tmp_path, lib, device):
+    from hymls_amd import driver
+    xml, ov = _write_case(tmp_path, "re1000")
+    prm = driver.read_parameters(xml)
+    assert prm["Problem"]["nx"] == 32 and prm["Driver"]["Read Linear System"] is True
+    assert prm["Solver"]["Iterative Solver"]["Convergence Tolerance"] == 1e-10
+    res = driver.run(xml, lib=lib, device=device)
+    s = res["solves"][0]
+    assert s["iterations"] <= 130 and s["residual"] < 1e-9 and s["error"] < 1e-7
+    assert [l[1] for l in res["levels"]] == [3072, 435]
+    res2 = driver.run(xml, ov, lib=lib, device=device)          # overlay file: one more level
+    assert [l[1] for l in res2["levels"]] == [3072, 435, 15] and res2["solves"][0]["error"] < 1e-7
+
+
+def test_driver_hostsim(tmp_path, hostsim_lib):
+    check(tmp_path, hostsim_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_driver_gpu(tmp_path, gpu_lib):
+    check(tmp_path, gpu_lib, "cuda")

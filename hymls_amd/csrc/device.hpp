@@ -193,6 +193,8 @@ void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* i
 // all separator blocks of a level in one launch (blocks of any order; heavy ones first)
 struct BlkD { const double* binv; const int32_t* ids; int32_t nb, pad; };
 void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, double* y);
+// in-place inverse (partial pivoting) of every block of the table, one launch
+void dense_invert_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, int32_t* flag);
 
 }  // namespace dev
 }  // namespace hymls

@@ -1562,11 +1562,14 @@ void sblock_extract(int32_t nS, int64_t npick, const int32_t* pick, const double
 }
 
 // in-place Gauss-Jordan inversion with partial pivoting, one workgroup per block
-__global__ void __launch_bounds__(256) k_dense_invert(int32_t nb, double* __restrict__ blocks, int32_t* flag) {
+// one workgroup per block; `all` != nullptr: blocks of any order from a descriptor table (one launch for a
+// whole level, so that the few large blocks of the coarser levels run side by side), else nblk blocks of order nb0
+__global__ void __launch_bounds__(256) k_dense_invert(int32_t nb0, double* __restrict__ blocks, const BlkD* __restrict__ all, int32_t* flag) {
   extern __shared__ int piv[];   // nb ints, then reduction scratch
   __shared__ double red_v[256];
   __shared__ int red_i[256];
-  double* A = blocks + (int64_t)blockIdx.x * nb * nb;
+  const int nb = all ? all[blockIdx.x].nb : nb0;
+  double* A = all ? const_cast<double*>(all[blockIdx.x].binv) : blocks + (int64_t)blockIdx.x * nb * nb;
   const int tid = threadIdx.x;
   for (int k = 0; k < nb; k++) {
     // pivot search in column k, rows k..nb-1
@@ -1618,7 +1621,12 @@ __global__ void __launch_bounds__(256) k_dense_invert(int32_t nb, double* __rest
 void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag) {
   if (nb <= 0 || nblk <= 0) return;
   const int bs = nb <= 64 ? 64 : 256;
-  hipLaunchKernelGGL(k_dense_invert, dim3(nblk), dim3(bs), (size_t)nb * sizeof(int), g_stream, nb, blocks, flag);
+  hipLaunchKernelGGL(k_dense_invert, dim3(nblk), dim3(bs), (size_t)nb * sizeof(int), g_stream, nb, blocks, (const BlkD*)nullptr, flag);
+  launch_check();
+}
+void dense_invert_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, int32_t* flag) {
+  if (nblk <= 0) return;
+  hipLaunchKernelGGL(k_dense_invert, dim3(nblk), dim3(256), (size_t)max_nb * sizeof(int), g_stream, 0, (double*)nullptr, blocks, flag);
   launch_check();
 }
 

@@ -1277,8 +1277,8 @@ void LevelSolver::compute() {
     // (Ifpack_DenseContainer::Compute -> dgetrf in the reference, SchurPreconditioner.cpp:284-291)
     const int64_t bl = (int64_t)B.nb * B.nb;
     dev::pull_sum_blocks(bl, B.nblk, B.d_pull_ptr, B.d_pull_base, d_ext_, B.d_binv);
-    dev::dense_invert(B.nb, B.nblk, B.d_binv, d_flag_);
   }
+  dev::dense_invert_all(n_blk_, d_blkd_, blk_max_nb_, d_flag_);
   int32_t flag = 0;
   dev::d2h(&flag, d_flag_, sizeof flag);
   HYMLS_CHECK(comm_->allsum(flag != 0) == 0, -4,

@@ -404,6 +404,10 @@ void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* i
   }
 }
 
+void dense_invert_all(int32_t nblk, const BlkD* blocks, int32_t, int32_t* flag) {
+  for (int b = 0; b < nblk; b++) dense_invert(blocks[b].nb, 1, const_cast<double*>(blocks[b].binv), flag);
+}
+
 void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t, const double* x, double* y) {
   std::vector<double> xs, out;
   for (int b = 0; b < nblk; b++) {

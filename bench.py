@@ -189,6 +189,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         bytes_all = [float(v) for v in t.tolist()]
 
+    hbm_used = None
+    if not args.hostsim:
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        hbm_used = (total_b - free_b) / 2**30
     krylov = None
     if args.krylov:
         S = hymls_amd.Solver(P, P, {"Krylov Method": "GMRES", "Iterative Solver": {
@@ -249,7 +253,7 @@ def main():
                            "sharded: %dx%dx%d boxes of %dx%dx%d cells, one per GPU; halo + V-sum exchange over torch.distributed (%s)"
                            % (px, py, pz, nx // px, ny // py, nz // pz, backend) if sharded else
                            (note or "%d replicas (one problem per GPU, no exchange)" % world)),
-                       "levels": lv, "initialize_s": t_init, "compute_s": t_comp},
+                       "levels": lv, "initialize_s": t_init, "compute_s": t_comp, "hbm_used_gib_rank0": hbm_used},
             "hbm_gbps": bytes_all[0] / (elapsed / args.steps) / 1e9,
             "apply_bytes": {"total": bytes_all[0], "interior_factors": bytes_all[1], "a12_a21": bytes_all[2],
                             "separator_blocks_ot": bytes_all[3], "coarse": bytes_all[4], "vectors": bytes_all[5]},

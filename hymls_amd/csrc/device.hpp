@@ -21,6 +21,9 @@ void d2d(void* dst, const void* src, size_t bytes);
 void zero(void* dst, size_t bytes);
 void sync();
 size_t mem_free();
+// process-wide setup scratch (frontal matrices, separator blocks, pivot-piece workspace): factorisations run one
+// after the other on the stream, so every batch borrows the same arena; grown on demand (synchronises when it grows)
+void* shared_scratch(size_t bytes);
 // event timing on the stream (seconds); ids are small integers
 void timer_start(int id);
 double timer_stop(int id);  // synchronises

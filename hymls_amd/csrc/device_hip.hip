@@ -70,6 +70,18 @@ void d2d(void* d, const void* s, size_t n) {
 }
 void zero(void* d, size_t n) { if (n) HIP_CHECK(hipMemsetAsync(d, 0, n, g_stream)); }
 void sync() { HIP_CHECK(hipStreamSynchronize(g_stream)); }
+static void* g_arena = nullptr;
+static size_t g_arena_cap = 0;
+void* shared_scratch(size_t bytes) {
+  if (bytes > g_arena_cap) {
+    sync();
+    if (g_arena) (void)hipFree(g_arena);
+    g_arena = nullptr; g_arena_cap = 0;
+    g_arena = alloc(bytes);
+    g_arena_cap = bytes;
+  }
+  return g_arena;
+}
 size_t mem_free() { size_t f = 0, t = 0; HIP_CHECK(hipMemGetInfo(&f, &t)); return f; }
 void timer_start(int id) {
   if (!g_ev_init) {

@@ -138,10 +138,10 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   batch.src = keep(dev::upload(h_src));
   batch.xoff = keep(dev::upload(h_xoff));
   batch.factor = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)nb * plan.factor_size) * sizeof(double)));
-  batch.scratch = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)chunk * plan.scratch_size) * sizeof(double)));
-  batch.sblock = with_sblock
-                     ? (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)chunk * plan.nS * plan.nS) * sizeof(double)))
-                     : nullptr;
+  // frontal scratch / separator blocks / pivot workspace are borrowed from the shared arena at factor time
+  scratch_need_ = std::max<int64_t>(1, (int64_t)chunk * plan.scratch_size);
+  sblock_need_ = with_sblock ? std::max<int64_t>(1, (int64_t)chunk * plan.nS * plan.nS) : 0;
+  batch.scratch = nullptr; batch.sblock = nullptr;
   batch.contrib = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)nb * plan.contrib_size) * sizeof(double)));
   batch.flag = (int32_t*)keep(dev::alloc(sizeof(int32_t)));
   dev::zero(batch.flag, sizeof(int32_t));
@@ -152,7 +152,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   if (any_big) {
     const int64_t np = (plan.max_w + dev::PIECE - 1) / dev::PIECE;
     batch.tmp_stride = np * 2 * dev::PIECE * dev::PIECE + 2LL * plan.max_w * dev::PIECE;
-    batch.tmp = (double*)keep(dev::alloc((size_t)chunk * batch.tmp_stride * sizeof(double)));
+    tmp_need_ = (int64_t)chunk * batch.tmp_stride;
     int64_t part_max = 0;
     for (auto& L : plan.big_levels) {
       d_big_lists.push_back(keep(dev::upload(L)));
@@ -180,7 +180,15 @@ std::vector<dev::FrontD> BatchedLU::kids_of(int s) const {
   return k;
 }
 
+void BatchedLU::bind_scratch() {
+  double* a = (double*)dev::shared_scratch((size_t)(scratch_need_ + sblock_need_ + tmp_need_) * sizeof(double));
+  batch.scratch = a;
+  batch.sblock = sblock_need_ ? a + scratch_need_ : nullptr;
+  batch.tmp = tmp_need_ ? a + scratch_need_ + sblock_need_ : nullptr;
+}
+
 void BatchedLU::factor_chunk(const double* kval, int32_t b0, int32_t nbc) {
+  bind_scratch();
   if (batch.sblock) dev::sblock_init(dplan, batch, b0, nbc, kval);
   for (size_t l = 0; l < plan.levels.size(); l++) {
     dev::factor_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), b0, nbc, kval);

@@ -42,7 +42,9 @@ struct BatchedLU {
   void upload(int64_t scratch_budget_doubles, bool with_sblock);
   // numeric factorisation of members [b0,b0+nbc) (scratch slots 0..nbc-1)
   void factor_chunk(const double* kval, int32_t b0, int32_t nbc);
-  void repack_chunk(int32_t b0, int32_t nbc);   // after factor_chunk and after the separator block was read
+  void repack_chunk(int32_t b0, int32_t nbc);
+  void bind_scratch();            // point batch.scratch / sblock / tmp into the shared setup arena
+  int64_t scratch_need_ = 0, sblock_need_ = 0, tmp_need_ = 0;   // doubles   // after factor_chunk and after the separator block was read
   void solve(double* x) const;    // forward + backward, all members, in place
   int32_t check_flag() const;
 };

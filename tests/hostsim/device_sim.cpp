@@ -21,6 +21,12 @@ void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
 void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
 void zero(void* d, size_t n) { std::memset(d, 0, n); }
 void sync() {}
+static void* g_arena = nullptr;
+static size_t g_arena_cap = 0;
+void* shared_scratch(size_t bytes) {
+  if (bytes > g_arena_cap) { std::free(g_arena); g_arena = std::malloc(bytes); g_arena_cap = bytes; }
+  return g_arena;
+}
 size_t mem_free() { return (size_t)1 << 40; }
 static std::chrono::steady_clock::time_point t0[16];
 void timer_start(int id) { t0[id] = std::chrono::steady_clock::now(); }

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <thread>
 #include <mutex>
+#include <atomic>
 #include <map>
 #include <unordered_map>
 
@@ -59,23 +60,31 @@ Csr drop_by_value(const Csr& A, double tol, int kind) {
   R.n = A.n;
   R.rowptr.assign(A.n + 1, 0);
   dvec diag(A.n, 0.0);
-  std::vector<char> has_diag(A.n, 0);
-  for (int i = 0; i < A.n; i++)
+  parallel_for(A.n, [&](int64_t i) {
     for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++)
-      if (A.col[e] == i) { diag[i] = A.val[e]; has_diag[i] = 1; }
-  for (int i = 0; i < A.n; i++) {
-    if (full_diag) { R.col.push_back(i); R.val.push_back(std::abs(diag[i]) > tol ? diag[i] : 0.0); }
+      if (A.col[e] == i) diag[i] = A.val[e];
+  });
+  // two passes over the rows (count, fill), rows in parallel
+  auto row = [&](int64_t i, int32_t* col, double* val) {
+    int32_t n = 0;
+    auto put = [&](int32_t j, double v) { if (col) { col[n] = j; val[n] = v; } n++; };
+    if (full_diag) put((int32_t)i, std::abs(diag[i]) > tol ? diag[i] : 0.0);
     for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++) {
       const int j = A.col[e];
       const bool isd = j == i;
       if (isd && full_diag) continue;
       const double scal = isd ? 1.0 : std::max(std::abs(diag[i]), std::abs(diag[j]));
       const double v = A.val[e];
-      if (std::abs(v) > scal * tol && std::abs(v) > tol) { R.col.push_back(j); R.val.push_back(v); }
-      else if (isd && zero_diag) { R.col.push_back(j); R.val.push_back(0.0); }
+      if (std::abs(v) > scal * tol && std::abs(v) > tol) put(j, v);
+      else if (isd && zero_diag) put(j, 0.0);
     }
-    R.rowptr[i + 1] = (int32_t)R.col.size();
-  }
+    return n;
+  };
+  parallel_for(A.n, [&](int64_t i) { R.rowptr[i + 1] = row(i, nullptr, nullptr); });
+  for (int i = 0; i < A.n; i++) R.rowptr[i + 1] += R.rowptr[i];
+  R.col.resize((size_t)R.rowptr[A.n]);
+  R.val.resize((size_t)R.rowptr[A.n]);
+  parallel_for(A.n, [&](int64_t i) { row(i, R.col.data() + R.rowptr[i], R.val.data() + R.rowptr[i]); });
   return R;
 }
 
@@ -540,36 +549,58 @@ void LevelSolver::initialize() {
   ivec row_of_internal(n1_);
   for (int i = 0; i < n; i++) if (intidx_[i] >= 0) row_of_internal[intidx_[i]] = i;
   a12_row_.assign(n1_ + 1, 0); a21_row_.assign(n2_ + 1, 0);
-  a12_col_.clear(); a12_src_.clear(); a21_col_.clear(); a21_src_.clear();
-  for (int t = 0; t < n1_; t++) {
+  // A12: count, prefix, fill (rows in parallel)
+  parallel_for(n1_, [&](int64_t t) {
     const int r = row_of_internal[t];
+    int32_t c = 0;
+    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) c += pos2_[K_.col[e]] >= 0;
+    a12_row_[t + 1] = c;
+  });
+  for (int t = 0; t < n1_; t++) a12_row_[t + 1] += a12_row_[t];
+  a12_col_.assign((size_t)a12_row_[n1_], 0); a12_src_.assign((size_t)a12_row_[n1_], 0);
+  parallel_for(n1_, [&](int64_t t) {
+    const int r = row_of_internal[t];
+    int32_t o = a12_row_[t];
     for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
       const int c = K_.col[e];
-      if (pos2_[c] >= 0) { a12_col_.push_back(pos2_[c]); a12_src_.push_back(e); }
+      if (pos2_[c] >= 0) { a12_col_[o] = pos2_[c]; a12_src_[o] = e; o++; }
     }
-    a12_row_[t + 1] = (int32_t)a12_col_.size();
-  }
+  });
+  // A21: ghost interior columns are numbered first (sequential over the few boundary rows), then count / fill
   std::vector<std::vector<int64_t>> want_int(comm_->size);
   std::vector<ivec> dst_int(comm_->size);
   ivec ghost_idx(dist ? n : 0, -1);
   ngi_ = 0;
-  for (int k = 0; k < n2_; k++) {
-    const int r = sep_row_[k];
-    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
-      const int c = K_.col[e];
-      if (intidx_[c] >= 0) { a21_col_.push_back(intidx_[c]); a21_src_.push_back(e); }
-      else if (dist && pos2_[c] < 0 && node_sd[c] >= 0) {
-        if (ghost_idx[c] < 0) {
+  if (dist)
+    for (int k = 0; k < n2_; k++) {
+      const int r = sep_row_[k];
+      for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
+        const int c = K_.col[e];
+        if (intidx_[c] < 0 && pos2_[c] < 0 && node_sd[c] >= 0 && ghost_idx[c] < 0) {
           ghost_idx[c] = n1_ + ngi_++;
           const int q = sd_rank_[node_sd[c]];
           want_int[q].push_back(gids_[c]);
           dst_int[q].push_back(ghost_idx[c]);
         }
-        a21_col_.push_back(ghost_idx[c]); a21_src_.push_back(e);
       }
     }
-    a21_row_[k + 1] = (int32_t)a21_col_.size();
-  }
+  auto a21_target = [&](int c) { return intidx_[c] >= 0 ? intidx_[c] : ((dist && pos2_[c] < 0) ? ghost_idx[c] : -1); };
+  parallel_for(n2_, [&](int64_t k) {
+    const int r = sep_row_[k];
+    int32_t c = 0;
+    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) c += a21_target(K_.col[e]) >= 0;
+    a21_row_[k + 1] = c;
+  });
+  for (int k = 0; k < n2_; k++) a21_row_[k + 1] += a21_row_[k];
+  a21_col_.assign((size_t)a21_row_[n2_], 0); a21_src_.assign((size_t)a21_row_[n2_], 0);
+  parallel_for(n2_, [&](int64_t k) {
+    const int r = sep_row_[k];
+    int32_t o = a21_row_[k];
+    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
+      const int t = a21_target(K_.col[e]);
+      if (t >= 0) { a21_col_[o] = t; a21_src_[o] = e; o++; }
+    }
+  });
   if (dist) {
     // x1 of the neighbours' interiors next to separators owned here; x2 of the separators owned elsewhere
     xch_int_.build(*comm_, want_int, dst_int, [&](int64_t g) { const int l = g2l_[g]; return l >= 0 ? intidx_[l] : -1; });
@@ -1174,31 +1205,33 @@ void LevelSolver::assemble_reduced(Csr& R, ivec& row_gids, dvec* tvn) {
     if (tvn) glob_tv_ = comm_->allgather(*tvn);
     const int64_t N = (int64_t)glob_gids_.size();
     HYMLS_CHECK(N < (int64_t)1 << 31, -2, "reduced matrix too large for 32-bit row numbers");
-    std::unordered_map<int32_t, int32_t> row_of;
-    row_of.reserve((size_t)N * 2);
-    for (int64_t i = 0; i < N; i++) HYMLS_CHECK(row_of.emplace(glob_gids_[i], (int32_t)i).second, -3, "separator owned by two ranks");
+    ivec row_of(ngid_, -1);     // gid -> global row
+    for (int64_t i = 0; i < N; i++) {
+      HYMLS_CHECK(row_of[glob_gids_[i]] < 0, -3, "separator owned by two ranks");
+      row_of[glob_gids_[i]] = (int32_t)i;
+    }
     glob_.n = (int32_t)N;
     glob_.rowptr.assign(N + 1, 0);
     for (int64_t i = 0; i < N; i++) glob_.rowptr[i + 1] = glob_.rowptr[i] + len[i];
     glob_.col.resize(colg.size());
     glob_perm_.resize(colg.size());
-    std::vector<std::pair<int32_t, int64_t>> row;
-    for (int64_t i = 0; i < N; i++) {
-      row.clear();
+    std::atomic<int> missing{0};
+    parallel_for(N, [&](int64_t i) {
+      std::vector<std::pair<int32_t, int64_t>> row;
       for (int64_t e = glob_.rowptr[i]; e < glob_.rowptr[i + 1]; e++) {
-        auto it = row_of.find(colg[e]);
-        HYMLS_CHECK(it != row_of.end(), -3, "reduced matrix refers to a node nobody owns");
-        row.emplace_back(it->second, e);
+        if (row_of[colg[e]] < 0) missing = 1;
+        row.emplace_back(row_of[colg[e]], e);
       }
       std::sort(row.begin(), row.end());
       for (size_t k = 0; k < row.size(); k++) { glob_.col[glob_.rowptr[i] + k] = row[k].first; glob_perm_[row[k].second] = glob_.rowptr[i] + (int64_t)k; }
-    }
+    });
+    HYMLS_CHECK(missing == 0, -3, "reduced matrix refers to a node nobody owns");
     glob_.val.assign(glob_.col.size(), 0.0);
     glob_ready_ = true;
   }
   dvec vals = comm_->allgather(red_.val);
   HYMLS_CHECK(vals.size() == glob_.val.size(), -3, "reduced matrix changed its pattern between two Compute calls");
-  for (size_t e = 0; e < vals.size(); e++) glob_.val[glob_perm_[e]] = vals[e];
+  parallel_for((int64_t)vals.size(), [&](int64_t e) { glob_.val[glob_perm_[e]] = vals[e]; }, 1 << 16);
   R = glob_;
   row_gids = glob_gids_;
 }

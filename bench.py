@@ -75,6 +75,9 @@ def main():
                     help="after the timed region: solve K x = b (b = K x_ex) with right-preconditioned GMRES on the device "
                          "(hymls_amd.Solver, relative residual 1e-8) and report the iteration count and time")
     ap.add_argument("--krylov-restart", type=int, default=100, help="GMRES restart length ('Num Blocks')")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL ONLY: all ranks use cuda:0 (with --backend gloo, staged through the host); "
+                         "the numbers are not a multi-GPU measurement and are marked so")
     ap.add_argument("--force-sharded", action="store_true",
                     help="N = 1: take the sharded code path anyway (one rank exchanging with itself over the transport): "
                          "measures what packing + callbacks + collectives cost per ApplyInverse")
@@ -98,6 +101,8 @@ def main():
         lib = None
         backend = args.backend
         assert torch.cuda.is_available(), "bench.py needs a GPU (hymls_amd has no CPU fallback)"
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     if args.force_sharded and world == 1:
@@ -178,7 +183,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     t_phase = [P.last_apply_seconds(i) for i in range(5)]   # averages over the timed steps
@@ -187,7 +192,7 @@ def main():
     bytes_all = [P.apply_bytes(i) for i in range(6)]
     bytes_rank0 = list(bytes_all)
     if world > 1:   # algorithmic bytes of the whole job = sum over the ranks
-        t = torch.tensor(bytes_all, dtype=torch.float64, device=dev)
+        t = torch.tensor(bytes_all, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         bytes_all = [float(v) for v in t.tolist()]
 
@@ -247,7 +252,8 @@ def main():
             "value": N_global * args.steps / elapsed, "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong" if sharded or world == 1 else "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic" if not args.hostsim else "synthetic (HOST SIMULATOR, TEST ONLY - not a measurement)",
+            "data": ("synthetic (HOST SIMULATOR, TEST ONLY - not a measurement)" if args.hostsim else
+                     "synthetic (REHEARSAL: all ranks share one GPU - not a multi-GPU measurement)" if args.share_gpu else "synthetic"),
             "config": {"workload": "GaleriExt Stokes3D %dx%dx%d (a=nx^2,b=1), %d DoF, HYMLS %d-level "
                                    "(Number of Levels=%d), Skew Cartesian sx=%d, Block Diagonal, 1 rhs"
                                    % (nx, ny, nz, N_global if sharded else N_local, levels + 1, levels, sx),

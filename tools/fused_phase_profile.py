@@ -1,5 +1,6 @@
+"""per-phase timing of k_interior_fused (HYMLS_MI_FUSED_PROF=1): python tools/fused_phase_profile.py  (needs a GPU)"""
 import sys, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, hymls_amd
 n = 128
 K = hymls_amd.generate_matrix("Stokes-C", n, n, n); tv = hymls_amd.generate_testvector(*K)

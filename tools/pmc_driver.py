@@ -1,8 +1,8 @@
 """PMC driver without torch (rocprofv3 --pmc crashes with the torch runtime in the process):
-ctypes only, host vectors.  usage: python3 tools_pmc_driver.py N SX LEVELS NAPPLY"""
+ctypes only, host vectors.  usage: python3 tools/pmc_driver.py N SX LEVELS NAPPLY"""
 import os, sys
 os.environ["HYMLS_MI_NO_TORCH"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import hymls_amd
 n, sx, levels, napply = (int(a) for a in sys.argv[1:5])

@@ -1,5 +1,6 @@
 """ad-hoc perf probe (not part of the product): time Initialize/Compute/ApplyInverse."""
-import sys, time, json
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import hymls_amd
 eq, n, sx, levels = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])

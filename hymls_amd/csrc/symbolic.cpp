@@ -205,9 +205,10 @@ void nd_cluster_recurse(NdCtx& c, const CluCtx& k, ivec& nodes) {
 
 void print_plan_stats(const ClassPlan& P, const char* label, int nmembers) {
   int nbig = 0, maxw = 0, maxr = 0;
-  for (auto& F : P.fronts) { nbig += F.big; maxw = std::max(maxw, F.w); maxr = std::max(maxr, F.ri + F.rs); }
-  std::fprintf(stderr, "[hymls_mi] %s: members %d nI %d nS %d fronts %zu (big %d) levels %zu max_w %d max_r %d nnz_factor %.3g scratch %.3g MB flops %.3g contrib %d level_rows %d\n",
-               label, nmembers, P.nI, P.nS, P.fronts.size(), nbig, P.levels.size(), maxw, maxr, (double)P.nnz_factor,
+  double wrs = 0;
+  for (auto& F : P.fronts) { nbig += F.big; maxw = std::max(maxw, F.w); maxr = std::max(maxr, F.ri + F.rs); wrs += 2.0 * F.w * F.rs; }
+  std::fprintf(stderr, "[hymls_mi] %s: members %d nI %d nS %d fronts %zu (big %d) levels %zu max_w %d max_r %d nnz_factor %.3g (separator panels 2 w rs: %.3g) scratch %.3g MB flops %.3g contrib %d level_rows %d\n",
+               label, nmembers, P.nI, P.nS, P.fronts.size(), nbig, P.levels.size(), maxw, maxr, (double)P.nnz_factor, wrs,
                8e-6 * (double)P.scratch_size, (double)P.flops_factor, P.contrib_size, P.max_level_rows);
 }
 

@@ -133,14 +133,16 @@ def test_merged_level_solve_path(hostsim_lib, monkeypatch, small_rows):
     assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-9
 
 
-@pytest.mark.parametrize("levels,tol", [(0, 1e-9), (1, 1e-8)])
-def test_nonsymmetric_navier_stokes_like(hostsim_lib, levels, tol):
+@pytest.mark.parametrize("levels,tol,re", [(0, 1e-9, 80.0), (1, 1e-8, 80.0), (1, 1e-8, 10000.0)])
+def test_nonsymmetric_navier_stokes_like(hostsim_lib, levels, tol, re):
     """unsymmetric values (convection) on the Stokes pattern: the LU without pivoting and the separate L- and
-    U-side panels against the oracle (SuperLU with partial pivoting)."""
+    U-side panels against the oracle (SuperLU with partial pivoting).  re = 10000: cell Reynolds number 625, the
+    velocity rows have lost diagonal dominance (diagonal / off-diagonal sum 0.14) -- robustness of the
+    pivot-free factorisation (BASELINE configs[3] "robustness at high Re")."""
     from common import add_convection
     n = 16
     A, tv = problem("Stokes-C", n)
-    A = add_convection(A, n, re=80.0)
+    A = add_convection(A, n, re=re)
     assert abs(A - A.T).max() > 1.0
     P = product_prec(A, tv, xml_params("Stokes-C", n, 8, levels, partitioner="Skew Cartesian"), hostsim_lib)
     O = oracle_prec(A, tv, "Stokes-C", n, 8, levels, partitioner="Skew Cartesian")

@@ -74,6 +74,8 @@ def load_library(path=None):
         "hymls_mi_initialize": (C.c_int, [H]),
         "hymls_mi_compute": (C.c_int, [H]),
         "hymls_mi_apply_inverse": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+        "hymls_mi_set_border": (C.c_int, [H, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+        "hymls_mi_apply_inverse_bordered": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
         "hymls_mi_apply": (C.c_int, [H, _F64P, _F64P]),
         "hymls_mi_matvec": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int]),
         "hymls_mi_is_initialized": (C.c_int, [H]),
@@ -339,6 +341,41 @@ class Preconditioner:
             X[...] = Xc
             return X
         return Xc
+
+    # --- BorderedOperator (reference src/HYMLS_BorderedOperator.hpp)
+    def SetBorder(self, V, W=None, C_=None):
+        """[K V; W' C]: V, W (n, m) arrays, C (m, m); W defaults to V, C to zero; V=None removes the border.
+        Compute() has to be called afterwards (reference src/HYMLS_Preconditioner.cpp:844-918)."""
+        if V is None:
+            self._check(self._lib.hymls_mi_set_border(self._h, 0, None, 0, None, 0, None))
+            self._m = 0
+            return 0
+        V = np.asfortranarray(np.asarray(V, dtype=np.float64).reshape(self._n, -1))
+        m = V.shape[1]
+        W = None if W is None else np.asfortranarray(np.asarray(W, dtype=np.float64).reshape(self._n, m))
+        Cm = None if C_ is None else np.asfortranarray(np.asarray(C_, dtype=np.float64).reshape(m, m))
+        self._check(self._lib.hymls_mi_set_border(self._h, m, V.ctypes.data, self._n, W.ctypes.data if W is not None else None,
+                                                  self._n, Cm.ctypes.data if Cm is not None else None))
+        self._m = m
+        return 0
+
+    def HaveBorder(self):
+        return getattr(self, "_m", 0) > 0
+
+    def ApplyInverseBordered(self, B, T):
+        """ApplyInverse(B, T, X, S): returns (X, S) with [K V; W' C] [X; S] ~ [B; T]; B a host array or a device tensor."""
+        m = getattr(self, "_m", 0)
+        T = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(m))
+        S = np.zeros(m)
+        if hasattr(B, "data_ptr"):
+            import torch
+            X = torch.empty_like(B)
+            self._check(self._lib.hymls_mi_apply_inverse_bordered(self._h, B.data_ptr(), T.ctypes.data, X.data_ptr(), S.ctypes.data, 1))
+            return X, S
+        Bc = np.ascontiguousarray(B, dtype=np.float64)
+        X = np.empty_like(Bc)
+        self._check(self._lib.hymls_mi_apply_inverse_bordered(self._h, Bc.ctypes.data, T.ctypes.data, X.ctypes.data, S.ctypes.data, 0))
+        return X, S
 
     def Apply(self, X, Y):
         return -1  # not implemented in the reference either

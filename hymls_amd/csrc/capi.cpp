@@ -241,17 +241,69 @@ int hymls_mi_apply_inverse(hymls_mi_t* h, const double* B, int64_t ldb, double* 
     h->d_x = (double*)dev::alloc(n * sizeof(double));
     h->buf_n = n;
   }
+  const int bm = h->top->border_size();
+  dvec tz(std::max(bm, 1), 0.0), s0(std::max(bm, 1), 0.0);
   for (int k = 0; k < nvec; k++) {
     if (on_device) {
-      h->top->apply_inverse(B + k * ldb, X + k * ldx);
+      if (bm) h->top->apply_inverse_bordered(B + k * ldb, tz.data(), X + k * ldx, s0.data());
+      else h->top->apply_inverse(B + k * ldb, X + k * ldx);
     } else {
       dev::h2d(h->d_b, B + k * ldb, n * sizeof(double));
-      h->top->apply_inverse(h->d_b, h->d_x);
+      if (bm) h->top->apply_inverse_bordered(h->d_b, tz.data(), h->d_x, s0.data());
+      else h->top->apply_inverse(h->d_b, h->d_x);
       dev::d2h(X + k * ldx, h->d_x, n * sizeof(double));
     }
   }
   h->n_apply++;
   if (!on_device) h->t_apply += now() - t0;
+  API_END(h)
+}
+
+int hymls_mi_set_border(hymls_mi_t* h, int m, const double* V, int64_t ldv, const double* W, int64_t ldw, const double* C) {
+  if (!h) return -2;
+  if (!h->initialized) {
+    int ierr = hymls_mi_initialize(h);
+    if (ierr) return ierr;
+  }
+  API_BEGIN
+  h->computed = false;
+  if (m <= 0 || !V) { h->top->set_border(0, nullptr, nullptr, nullptr); return 0; }
+  const int64_t n = h->top->num_owned();
+  HYMLS_CHECK(ldv >= n && (!W || ldw >= n), -2, "SetBorder: leading dimension smaller than the number of rows");
+  dvec v((size_t)n * m), w((size_t)n * m);
+  for (int j = 0; j < m; j++) {
+    std::copy(V + j * ldv, V + j * ldv + n, v.begin() + (size_t)j * n);
+    const double* wj = W ? W + j * ldw : V + j * ldv;
+    std::copy(wj, wj + n, w.begin() + (size_t)j * n);
+  }
+  double* dv = dev::upload(v);
+  double* dw = dev::upload(w);
+  try { h->top->set_border(m, dv, dw, C); } catch (...) { dev::free(dv); dev::free(dw); throw; }
+  dev::free(dv); dev::free(dw);
+  API_END(h)
+}
+
+int hymls_mi_apply_inverse_bordered(hymls_mi_t* h, const double* B, const double* T, double* X, double* S, int on_device) {
+  if (!h) return -2;
+  API_BEGIN
+  HYMLS_CHECK(h->computed, -1, "The preconditioner has not yet been computed.");
+  const int64_t n = h->top->num_owned();
+  const int m = h->top->border_size();
+  dvec t0(std::max(m, 1), 0.0), s0(std::max(m, 1), 0.0);
+  const double* Tp = T ? T : t0.data();
+  double* Sp = S ? S : s0.data();
+  if (on_device) {
+    h->top->apply_inverse_bordered(B, Tp, X, Sp);
+  } else {
+    if (h->buf_n < n) {
+      dev::free(h->d_b); dev::free(h->d_x);
+      h->d_b = (double*)dev::alloc(n * sizeof(double)); h->d_x = (double*)dev::alloc(n * sizeof(double)); h->buf_n = n;
+    }
+    dev::h2d(h->d_b, B, n * sizeof(double));
+    h->top->apply_inverse_bordered(h->d_b, Tp, h->d_x, Sp);
+    dev::d2h(X, h->d_x, n * sizeof(double));
+  }
+  h->n_apply++;
   API_END(h)
 }
 

@@ -193,6 +193,14 @@ void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag);
 void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* ids,
                   const double* x, double* y);
 
+// ---- bordered systems (setup-time helpers; not on the ApplyInverse fast path)
+// x . y with a fixed-order two-stage reduction; synchronises the stream and returns the value to the host
+double dot(int64_t n, const double* x, const double* y);
+// x <- A11^{-T} x for every member of the batch (transposed solve with the same panels: forward with U^T,
+// backward with L^T); order[nfronts]: fronts in elimination order (children before parents); one workgroup per
+// member walks the tree sequentially -- used m times per Compute for the border W
+void solve_transposed(const PlanD& P, const BatchD& B, const int32_t* order, int32_t nfronts, int32_t max_rows, double* x);
+
 // all separator blocks of a level in one launch (blocks of any order; heavy ones first)
 struct BlkD { const double* binv; const int32_t* ids; int32_t nb, pad; };
 void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, double* y);

@@ -1221,6 +1221,88 @@ void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, c
   launch_check();
 }
 
+// ------------------------------------------------------------------ bordered systems
+__global__ void __launch_bounds__(256) k_dot_partial(int64_t n, const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ part) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * y[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+double dot(int64_t n, const double* x, const double* y) {
+  if (n <= 0) return 0.0;
+  static double* dpart = nullptr;
+  if (!dpart) dpart = (double*)alloc(1024 * sizeof(double));
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+  hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, g_stream, n, x, y, dpart);
+  launch_check();
+  double h[1024];
+  d2h(h, dpart, nb * sizeof(double));
+  double s = 0.0;
+  for (int i = 0; i < nb; i++) s += h[i];
+  return s;
+}
+
+// panel entries of a front in either layout (device.hpp)
+struct PanelRef {
+  const double* lp; const double* q; int64_t w, ri, ld; int packed;
+  __device__ double linv(int i, int k) const { return packed ? lp[packed_lower(w, i, k)] : lp[i + ld * k]; }            // i > k
+  __device__ double uinv(int i, int k) const { return packed ? lp[packed_upper(w, ri, i, k)] : lp[i + ld * k]; }        // i <= k
+  __device__ double pl(int j, int k) const { return packed ? lp[packed_l21(w, ri, j, k)] : lp[(w + j) + ld * k]; }       // row j of L21 L11^{-1}
+  __device__ double qu(int i, int j) const { return q[i + w * j]; }                                                     // U11^{-1} U12
+};
+__global__ void __launch_bounds__(256) k_solve_transposed(PlanD P, BatchD B, const int32_t* __restrict__ order, int32_t nfronts,
+                                                           double* __restrict__ x) {
+  extern __shared__ double a[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double* xb = x + B.xoff[b];
+  double* cb = B.contrib + (int64_t)b * P.contrib_size;
+  const double* fac = B.factor + (int64_t)b * P.factor_size;
+  // forward with U^T: z = U11^{-T} a, contributions a_upd - (U11^{-1} U12)^T a
+  for (int q = 0; q < nfronts; q++) {
+    const FrontD F = P.fronts[order[q]];
+    const int w = F.w, ri = F.ri;
+    const PanelRef R{fac + F.lp_off, fac + F.q_off, w, ri, w + ri, P.packed};
+    for (int j = tid; j < w + ri; j += 256) {
+      double v = j < w ? xb[F.c0 + j] : 0.0;
+      for (int t = P.asm_ptr[F.a_off + j]; t < P.asm_ptr[F.a_off + j + 1]; t++) v += cb[P.asm_src[t]];
+      a[j] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < w + ri; i += 256) {
+      double s = 0.0;
+      if (i < w) { for (int k = 0; k <= i; k++) s += R.uinv(k, i) * a[k]; xb[F.c0 + i] = s; }
+      else { for (int k = 0; k < w; k++) s += R.qu(k, i - w) * a[k]; cb[F.c_off + i - w] = a[i] - s; }
+    }
+    __syncthreads();
+  }
+  // backward with L^T: x = L11^{-T} z - (L21 L11^{-1})^T x_ancestors
+  for (int q = nfronts - 1; q >= 0; q--) {
+    const FrontD F = P.fronts[order[q]];
+    const int w = F.w, ri = F.ri;
+    const PanelRef R{fac + F.lp_off, fac + F.q_off, w, ri, w + ri, P.packed};
+    const int32_t* idx = P.fidx + F.idx_off;
+    for (int k = tid; k < w + ri; k += 256) a[k] = k < w ? xb[F.c0 + k] : xb[idx[k]];
+    __syncthreads();
+    for (int i = tid; i < w; i += 256) {
+      double s = a[i];
+      for (int k = i + 1; k < w; k++) s += R.linv(k, i) * a[k];
+      for (int j = 0; j < ri; j++) s -= R.pl(j, i) * a[w + j];
+      xb[F.c0 + i] = s;
+    }
+    __syncthreads();
+  }
+}
+void solve_transposed(const PlanD& P, const BatchD& B, const int32_t* order, int32_t nfronts, int32_t max_rows, double* x) {
+  if (B.nb <= 0 || nfronts <= 0) return;
+  const size_t shm = (size_t)max_rows * sizeof(double);
+  if (shm > 64 * 1024) throw Error(-99, "front too large for the transposed solve (bordered systems)");
+  hipLaunchKernelGGL(k_solve_transposed, dim3(B.nb), dim3(256), shm, g_stream, P, B, order, nfronts, x);
+  launch_check();
+}
+
 // ------------------------------------------------------------------ packed panels
 // one workgroup per (front, member): copy the (w+ri) x w panel to the frontal scratch of the member's slot,
 // write it back in the packed order (device.hpp)

@@ -284,13 +284,13 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
 }
 
 DirectSolver::~DirectSolver() {
-  dev::free(d_val_); dev::free(d_z_); dev::free(d_perm_); dev::free(d_fix_);
+  dev::free(d_val_); dev::free(d_z_); dev::free(d_perm_); dev::free(d_fix_); dev::free(d_bZ_); dev::free(d_bW_);
 }
 
-void DirectSolver::apply_inverse(const double* b, double* x) {
+void DirectSolver::solve(const double* b, double* x, bool zero_fixed) {
   if (n_ == 0) return;
   dev::gather(n_, d_perm_, b, d_z_);
-  if (!fix_lids_.empty()) {
+  if (zero_fixed && !fix_lids_.empty()) {
     // zero the Dirichlet right-hand sides: scatter zeros
     static thread_local double* zeros = nullptr;
     if (!zeros) { zeros = (double*)dev::alloc(16 * sizeof(double)); dev::zero(zeros, 16 * sizeof(double)); }
@@ -298,6 +298,53 @@ void DirectSolver::apply_inverse(const double* b, double* x) {
   }
   lu_->solve(d_z_);
   dev::scatter(n_, d_perm_, d_z_, x);
+}
+
+void DirectSolver::apply_inverse(const double* b, double* x) { solve(b, x, true); }
+
+// CoarseSolver with a border (reference src/HYMLS_CoarseSolver.cpp:196-260,454-560): the reference factors the
+// AugmentedMatrix [A V; W' C]; here A (with its Dirichlet fixes) is already factored, so the same solution is
+// obtained by block elimination: Z = A^{-1} V once, then y = (C - W' Z)^{-1} (T - W' A^{-1} b), x = A^{-1} b - Z y.
+// (A has to be nonsingular, i.e. "Fix Pressure Level" stays on for Stokes problems.)
+void DirectSolver::set_border(int m, const double* dV, const double* dW, const double* C) {
+  dev::free(d_bZ_); dev::free(d_bW_);
+  d_bZ_ = d_bW_ = nullptr;
+  bm_ = 0; bMinv_.clear();
+  if (m <= 0 || n_ == 0) return;
+  bm_ = m;
+  d_bZ_ = (double*)dev::alloc((size_t)n_ * m * sizeof(double));
+  d_bW_ = (double*)dev::alloc((size_t)n_ * m * sizeof(double));
+  dev::d2d(d_bW_, dW, (size_t)n_ * m * sizeof(double));
+  for (int j = 0; j < m; j++) solve(dV + (size_t)j * n_, d_bZ_ + (size_t)j * n_, false);
+  // M = C - W' Z (m x m, column-major), inverted on the host with partial pivoting
+  dvec M((size_t)m * m);
+  for (int j = 0; j < m; j++)
+    for (int i = 0; i < m; i++) M[i + (size_t)m * j] = C[i + (size_t)m * j] - dev::dot(n_, d_bW_ + (size_t)i * n_, d_bZ_ + (size_t)j * n_);
+  bMinv_.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; i++) bMinv_[i + (size_t)m * i] = 1.0;
+  for (int k = 0; k < m; k++) {
+    int p = k;
+    for (int i = k + 1; i < m; i++) if (std::abs(M[i + (size_t)m * k]) > std::abs(M[p + (size_t)m * k])) p = i;
+    HYMLS_CHECK(M[p + (size_t)m * k] != 0.0 && std::isfinite(M[p + (size_t)m * k]), -4, "singular bordered coarse system");
+    if (p != k) for (int j = 0; j < m; j++) { std::swap(M[k + (size_t)m * j], M[p + (size_t)m * j]); std::swap(bMinv_[k + (size_t)m * j], bMinv_[p + (size_t)m * j]); }
+    const double ip = 1.0 / M[k + (size_t)m * k];
+    for (int j = 0; j < m; j++) { M[k + (size_t)m * j] *= ip; bMinv_[k + (size_t)m * j] *= ip; }
+    for (int i = 0; i < m; i++) {
+      if (i == k) continue;
+      const double f = M[i + (size_t)m * k];
+      if (f == 0.0) continue;
+      for (int j = 0; j < m; j++) { M[i + (size_t)m * j] -= f * M[k + (size_t)m * j]; bMinv_[i + (size_t)m * j] -= f * bMinv_[k + (size_t)m * j]; }
+    }
+  }
+}
+
+void DirectSolver::apply_inverse_bordered(const double* b, const double* T, double* x, double* S) {
+  if (bm_ == 0) { apply_inverse(b, x); return; }
+  solve(b, x, false);                       // (the augmented system of the reference does not zero the fixed rows)
+  dvec r(bm_);
+  for (int i = 0; i < bm_; i++) r[i] = T[i] - dev::dot(n_, d_bW_ + (size_t)i * n_, x);
+  for (int i = 0; i < bm_; i++) { S[i] = 0.0; for (int j = 0; j < bm_; j++) S[i] += bMinv_[i + (size_t)bm_ * j] * r[j]; }
+  for (int j = 0; j < bm_; j++) dev::axpby(n_, -S[j], d_bZ_ + (size_t)j * n_, 1.0, x);
 }
 
 void DirectSolver::add_stats(ApplyStats& st, bool) const {
@@ -361,6 +408,9 @@ LevelSolver::~LevelSolver() {
   for (void* q : ptrs) dev::free(q);
   dev::free(d_fsubs_); dev::free(d_fplans_);
   dev::free(d_blkd_);
+  { void* bp[] = {d_bVu_, d_bWu_, d_bW1_, d_bQ1_, d_bSV_, d_bSW_, d_bNV_, d_bNW_, d_btmp_, d_a12t_row_, d_a12t_col_, d_a12t_src_, d_a12t_val_};
+    for (void* q : bp) dev::free(q);
+    for (int32_t* q : d_orders_) dev::free(q); }
   dev::free(d_mv_row_); dev::free(d_mv_col_); dev::free(d_mv_src_); dev::free(d_mv_node_); dev::free(d_mv_val_); dev::free(d_mv_x_);
   dev::free(d_lsubs_); dev::free(d_lfw_); dev::free(d_lbw_); dev::free(d_ytmp_);
   for (auto& b : blocks_) { dev::free(b.d_binv); dev::free(b.d_ids); dev::free(b.d_pull_ptr); dev::free(b.d_pull_base); }
@@ -1294,6 +1344,7 @@ void LevelSolver::compute() {
   HYMLS_CHECK(comm_->allsum(bad) == 0, -4, "subdomain factorisation hit a zero or non-finite pivot (level " +
                                                std::to_string(level_) + ")");
   lap("factor + transform + extract");
+  compute_border();
   exchange_records();
   // ---- assemble what is kept of the Schur complement
   dev::pull_sum((int64_t)red_.col.size(), d_red_pull_ptr_, d_red_pull_idx_, d_ext_, d_red_val_);
@@ -1310,6 +1361,7 @@ void LevelSolver::compute() {
     if (dist) next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_));
     else next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &sep_sd_ptr_, &sep_sd_, &sd_center_));
     build_handoff(next_gids);
+    set_next_border();
     return;
   }
   dev::zero(d_flag_, sizeof(int32_t));
@@ -1355,6 +1407,7 @@ void LevelSolver::compute() {
     }
     next_level_->profiling = false;  // phases are reported for the top level only
     lap("next level initialize");
+    set_next_border();
     next_level_->compute();
     lap("next level compute");
   } else {
@@ -1371,6 +1424,7 @@ void LevelSolver::compute() {
       next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &cp, &cl, &sd_center_));
     }
     build_handoff(next_gids);
+    set_next_border();
     lap("coarse solver");
   }
 }
@@ -1492,6 +1546,147 @@ void LevelSolver::build_matvec() {
   d_mv_val_ = (double*)dev::alloc(std::max<size_t>(1, col.size()) * sizeof(double));
   d_mv_x_ = (double*)dev::alloc((size_t)std::max(n, 1) * sizeof(double));
   mv_ready_ = true;
+}
+
+// ------------------------------------------------------------------ bordered systems [K V; W' C]
+// (BorderedOperator interface of HYMLS::Preconditioner, reference src/HYMLS_Preconditioner.cpp:519-588,844-918,
+// 930-1070 and of the SchurPreconditioner, src/HYMLS_SchurPreconditioner.cpp:631-664,1517-1617)
+void LevelSolver::set_border(int m, const double* dV, const double* dW, const double* C) {
+  HYMLS_CHECK(!comm_->distributed() || m <= 0, -99, "bordered systems are not implemented for sharded runs");
+  HYMLS_CHECK(initialized_, -1, "SetBorder needs an initialized preconditioner");
+  void* ptrs[] = {d_bVu_, d_bWu_, d_bW1_, d_bQ1_, d_bSV_, d_bSW_, d_bNV_, d_bNW_, d_btmp_};
+  for (void* q : ptrs) dev::free(q);
+  d_bVu_ = d_bWu_ = d_bW1_ = d_bQ1_ = d_bSV_ = d_bSW_ = d_bNV_ = d_bNW_ = d_btmp_ = nullptr;
+  bm_ = 0;
+  if (m <= 0) return;
+  bm_ = m;
+  const size_t n = (size_t)(n1_ + n2_);
+  d_bVu_ = (double*)dev::alloc(n * m * sizeof(double));
+  d_bWu_ = (double*)dev::alloc(n * m * sizeof(double));
+  dev::d2d(d_bVu_, dV, n * m * sizeof(double));
+  dev::d2d(d_bWu_, dW ? dW : dV, n * m * sizeof(double));
+  bC_.assign((size_t)m * m, 0.0);
+  if (C) bC_.assign(C, C + (size_t)m * m);
+  d_bW1_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)n1_ * m) * sizeof(double));
+  d_bQ1_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)n1_ * m) * sizeof(double));
+  d_bSV_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)n2_ * m) * sizeof(double));
+  d_bSW_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)n2_ * m) * sizeof(double));
+  d_btmp_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)std::max(n1_, n2_)) * sizeof(double));
+  const size_t ng = vs_.size();
+  d_bNV_ = (double*)dev::alloc(std::max<size_t>(1, ng * m) * sizeof(double));
+  d_bNW_ = (double*)dev::alloc(std::max<size_t>(1, ng * m) * sizeof(double));
+  if (!d_a12t_row_) {
+    // A12^T (separators x interiors) for W2 - A12' (A11' \ W1)
+    const int ns = n2_ + ngs_;
+    ivec row(ns + 1, 0), col(a12_col_.size()), src(a12_col_.size());
+    for (int32_t c : a12_col_) row[c + 1]++;
+    for (int i = 0; i < ns; i++) row[i + 1] += row[i];
+    ivec fill(row.begin(), row.end() - 1);
+    for (int t = 0; t < n1_; t++)
+      for (int e = a12_row_[t]; e < a12_row_[t + 1]; e++) { const int o = fill[a12_col_[e]]++; col[o] = t; src[o] = a12_src_[e]; }
+    d_a12t_row_ = dev::upload(row); d_a12t_col_ = dev::upload(col); d_a12t_src_ = dev::upload(src);
+    a12t_nnz_ = (int64_t)col.size();
+    d_a12t_val_ = (double*)dev::alloc(std::max<size_t>(1, col.size()) * sizeof(double));
+    for (auto& cp : cls_) {
+      ivec order;
+      int32_t rows = 1;
+      for (size_t l = 0; l < cp->lu.plan.levels.size(); l++) {
+        order.insert(order.end(), cp->lu.plan.levels[l].begin(), cp->lu.plan.levels[l].end());
+        order.insert(order.end(), cp->lu.plan.big_levels[l].begin(), cp->lu.plan.big_levels[l].end());
+      }
+      for (auto& F : cp->lu.plan.fronts) rows = std::max(rows, F.w + F.ri);
+      d_orders_.push_back(dev::upload(order));
+      order_rows_.push_back(rows);
+    }
+  }
+}
+
+void LevelSolver::interior_solve_transposed(double* x1) {
+  for (size_t c = 0; c < cls_.size(); c++) {
+    Cls& C = *cls_[c];
+    if (C.lu.plan.nI == 0) continue;
+    dev::solve_transposed(C.lu.dplan, C.lu.batch, d_orders_[c], (int32_t)C.lu.plan.fronts.size(), order_rows_[c], x1);
+  }
+}
+
+// ComputeBorder: Q1 = A11 \ V1, border of the Schur system SV = V2 - A21 Q1, SW = W2 - A12' (A11' \ W1),
+// SC = C - W1' Q1; the SchurPreconditioner transforms SV and SW with the OT and hands their V-sum rows to the next level
+void LevelSolver::compute_border() {
+  if (bm_ == 0) return;
+  const int m = bm_;
+  dev::gather(a12t_nnz_, d_a12t_src_, d_kval_, d_a12t_val_);
+  for (int j = 0; j < m; j++) {
+    const double* vu = d_bVu_ + (size_t)j * (n1_ + n2_);
+    const double* wu = d_bWu_ + (size_t)j * (n1_ + n2_);
+    double* q1 = d_bQ1_ + (size_t)j * n1_;
+    double* w1 = d_bW1_ + (size_t)j * n1_;
+    double* sv = d_bSV_ + (size_t)j * n2_;
+    double* sw = d_bSW_ + (size_t)j * n2_;
+    dev::gather(n1_, d_inperm_, vu, q1);
+    dev::gather(n2_, d_inperm_ + n1_, vu, sv);
+    dev::gather(n1_, d_inperm_, wu, w1);
+    dev::gather(n2_, d_inperm_ + n1_, wu, sw);
+    interior_solve(q1);                                                               // Q1 = A11 \ V1
+    dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, q1, sv, -1.0, 1.0);            // SV = V2 - A21 Q1
+    dev::d2d(d_btmp_, w1, (size_t)n1_ * sizeof(double));
+    interior_solve_transposed(d_btmp_);                                               // A11' \ W1
+    dev::spmv(n2_, d_a12t_row_, d_a12t_col_, d_a12t_val_, d_btmp_, sw, -1.0, 1.0);    // SW = W2 - A12' (...)
+  }
+  bSC_ = bC_;
+  for (int j = 0; j < m; j++)
+    for (int i = 0; i < m; i++) bSC_[i + (size_t)m * j] -= dev::dot(n1_, d_bW1_ + (size_t)i * n1_, d_bQ1_ + (size_t)j * n1_);
+  if (!direct_schur_) {
+    const int ng = (int)vs_.size();
+    for (int j = 0; j < m; j++) {
+      dev::ot_apply(ng, d_gptr_, d_otw_, d_bSV_ + (size_t)j * n2_);
+      dev::ot_apply(ng, d_gptr_, d_otw_, d_bSW_ + (size_t)j * n2_);
+      dev::gather(ng, d_vs_, d_bSV_ + (size_t)j * n2_, d_bNV_ + (size_t)j * ng);
+      dev::gather(ng, d_vs_, d_bSW_ + (size_t)j * n2_, d_bNW_ + (size_t)j * ng);
+    }
+  }
+}
+
+// the next level (or the coarse / direct Schur solver) gets its border before it is computed
+void LevelSolver::set_next_border() {
+  if (!next_) return;
+  if (bm_ == 0) { next_->set_border(0, nullptr, nullptr, nullptr); return; }
+  if (direct_schur_) next_->set_border(bm_, d_bSV_, d_bSW_, bSC_.data());
+  else next_->set_border(bm_, d_bNV_, d_bNW_, bSC_.data());
+}
+
+void LevelSolver::schur_apply_bordered(double* rhs2, const double* q, double* x2, double* S) {
+  if (direct_schur_) { next_->apply_inverse_bordered(rhs2, q, x2, S); return; }
+  const int ng = (int)vs_.size(), m = bm_;
+  dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);
+  dev::zero(x2, (size_t)n2_ * sizeof(double));                          // V-sum entries are zero in W'(M11 \ f1)
+  dev::blocks_apply_all(n_blk_, d_blkd_, blk_max_nb_, rhs2, x2);
+  dvec tc(m);
+  for (int j = 0; j < m; j++) tc[j] = q[j] - dev::dot(n2_, d_bSW_ + (size_t)j * n2_, x2);
+  dev::gather(ng, d_vs_, rhs2, d_vrhs_);
+  next_->apply_inverse_bordered(d_vrhs_, tc.data(), d_vsol_, S);
+  dev::scatter(ng, d_vs_, d_vsol_, x2);
+  dev::ot_apply(ng, d_gptr_, d_otw_, x2);
+}
+
+void LevelSolver::apply_inverse_bordered(const double* b, const double* T, double* x, double* S) {
+  if (bm_ == 0) { apply_inverse(b, x); return; }
+  HYMLS_CHECK(next_ != nullptr, -1, "The preconditioner has not yet been computed.");
+  const int m = bm_;
+  double* z1 = d_z_;
+  double* z2 = d_z_ + n1_ + ngi_;
+  dev::gather(n1_, d_inperm_, b, z1);
+  dev::gather(n2_, d_inperm_ + n1_, b, z2);
+  interior_solve(z1);                                                               // x1 = A11 \ b1
+  dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1, z2, -1.0, 1.0);            // b2 - A21 x1
+  dvec q(m);
+  for (int j = 0; j < m; j++) q[j] = T[j] - dev::dot(n1_, d_bW1_ + (size_t)j * n1_, z1);   // T - W1' x1
+  schur_apply_bordered(z2, q.data(), d_t2_, S);
+  dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0);
+  interior_solve(d_t1_);
+  dev::axpby(n1_, -1.0, d_t1_, 1.0, z1);                                            // x1 -= A11 \ (A12 x2)
+  for (int j = 0; j < m; j++) dev::axpby(n1_, -S[j], d_bQ1_ + (size_t)j * n1_, 1.0, z1);   // x1 -= Q1 S
+  dev::scatter(n1_, d_inperm_, z1, x);
+  dev::scatter(n2_, d_inperm_ + n1_, d_t2_, x);
 }
 
 void LevelSolver::matvec(const double* x, double* y) {

@@ -53,6 +53,11 @@ class Operator {  // something with ApplyInverse on device vectors in its own ro
  public:
   virtual ~Operator() {}
   virtual void apply_inverse(const double* b, double* x) = 0;
+  // BorderedOperator (reference src/HYMLS_BorderedOperator.hpp): [K V; W' C]; V, W: device arrays (size() x m,
+  // column-major, the operator's vector layout), C: host m x m column-major; m = 0 removes the border.  Takes effect
+  // with the next compute of the owner.  apply_inverse_bordered: T and S are host vectors of length m.
+  virtual void set_border(int m, const double* dV, const double* dW, const double* C) = 0;
+  virtual void apply_inverse_bordered(const double* b, const double* T, double* x, double* S) = 0;
   virtual int64_t size() const = 0;
   virtual void add_stats(ApplyStats& st, bool as_coarse) const = 0;
 };
@@ -65,11 +70,18 @@ class DirectSolver : public Operator {
                const ivec* clu_ptr = nullptr, const ivec* clu = nullptr, const ivec* clu_coord = nullptr);
   ~DirectSolver() override;
   void apply_inverse(const double* b, double* x) override;
+  void set_border(int m, const double* dV, const double* dW, const double* C) override;
+  void apply_inverse_bordered(const double* b, const double* T, double* x, double* S) override;
   int64_t size() const override { return n_; }
   void add_stats(ApplyStats& st, bool as_coarse) const override;
 
  private:
+  void solve(const double* b, double* x, bool zero_fixed);
   int32_t n_ = 0;
+  // border: x = A^{-1} b - Z y, y = (C - W' Z)^{-1} (T - W' A^{-1} b), Z = A^{-1} V
+  int bm_ = 0;
+  double *d_bZ_ = nullptr, *d_bW_ = nullptr;
+  dvec bMinv_;
   std::unique_ptr<BatchedLU> lu_;
   double* d_val_ = nullptr;
   double* d_z_ = nullptr;
@@ -98,6 +110,10 @@ class LevelSolver : public Operator {
   void set_values(const dvec& val);     // SetMatrix with unchanged pattern
   // b, x: this rank's owned rows (interiors of its subdomains + separators it owns) in the order of owned_gids()
   void apply_inverse(const double* b, double* x) override;
+  void set_border(int m, const double* dV, const double* dW, const double* C) override;
+  void apply_inverse_bordered(const double* b, const double* T, double* x, double* S) override;
+  bool have_border() const { return bm_ > 0; }
+  int border_size() const { return bm_; }
   int64_t size() const override { return global_n_; }
   void add_stats(ApplyStats& st, bool as_coarse) const override;
   // y = K x on the rows this rank owns (vectors in the layout of apply_inverse); sharded: collective, the values
@@ -130,6 +146,20 @@ class LevelSolver : public Operator {
   void next_apply(const double* rhs, double* sol);
   void build_handoff(const ivec& next_owned);
   void interior_solve(double* x1);
+  void interior_solve_transposed(double* x1);
+  void compute_border();
+  void set_next_border();
+  void schur_apply_bordered(double* rhs2, const double* q, double* x2, double* S);
+  // border (one rank only): user-layout copies, their interior / separator parts, A11^{-1} V1, transformed Schur border
+  int bm_ = 0;
+  dvec bC_, bSC_;
+  double *d_bVu_ = nullptr, *d_bWu_ = nullptr;
+  double *d_bW1_ = nullptr, *d_bQ1_ = nullptr, *d_bSV_ = nullptr, *d_bSW_ = nullptr, *d_bNV_ = nullptr, *d_bNW_ = nullptr, *d_btmp_ = nullptr;
+  int32_t *d_a12t_row_ = nullptr, *d_a12t_col_ = nullptr, *d_a12t_src_ = nullptr;
+  double* d_a12t_val_ = nullptr;
+  int64_t a12t_nnz_ = 0;
+  std::vector<int32_t*> d_orders_;     // per class: fronts in elimination order
+  ivec order_rows_;                    // per class: max w + ri
 
   Params p_;
   int level_;

@@ -115,6 +115,20 @@ int hymls_mi_compute(hymls_mi_t* h);
 int hymls_mi_apply_inverse(hymls_mi_t* h, const double* B, int64_t ldb,
                            double* X, int64_t ldx, int nvec, int on_device);
 
+/* ---- bordered systems: HYMLS::BorderedOperator (reference src/HYMLS_BorderedOperator.hpp,
+ * src/HYMLS_Preconditioner.cpp:844-918 SetBorder, :519-588 ComputeBorder, :930-1070 bordered ApplyInverse)
+ * [K V; W' C] [x; s] = [b; t].  V, W: host arrays n x m, column-major with leading dimensions ldv/ldw
+ * (W == NULL: W = V), C: m x m column-major (NULL: zero).  m == 0 or V == NULL removes the border.  Call after
+ * Initialize; Compute has to be called afterwards (as in the reference).  One rank only (returns -99 on a
+ * sharded handle). */
+int hymls_mi_set_border(hymls_mi_t* h, int m, const double* V, int64_t ldv, const double* W, int64_t ldw,
+                        const double* C);
+/* ApplyInverse(B, T, X, S): B, X one vector (host or device as on_device says), T, S host arrays of m doubles.
+ * With a border set, plain hymls_mi_apply_inverse solves with T = 0 and drops S (the reference's
+ * "expected behavior for standard ApplyInverse() of a BorderedOperator", SchurPreconditioner.cpp:1017-1025). */
+int hymls_mi_apply_inverse_bordered(hymls_mi_t* h, const double* B, const double* T, double* X, double* S,
+                                    int on_device);
+
 /* Epetra_Operator::Apply: not implemented in the reference (returns -1,
  * src/HYMLS_Preconditioner.cpp:585-592); same here. */
 int hymls_mi_apply(hymls_mi_t* h, const double* X, double* Y);

@@ -131,6 +131,20 @@ class CoarseSolver:
         self.S = S.tocsc()
         self.n = self.S.shape[0]
         self.lu = spla.splu(self.S) if self.n else None
+        self.border = None
+
+    def set_border(self, V, W, C):
+        """CoarseSolver::SetBorder + the bordered branch of Compute (src/HYMLS_CoarseSolver.cpp:196-260,425-445):
+        the border goes explicitly into an AugmentedMatrix [S V; W' C] that is factored by the direct solver."""
+        m = V.shape[1]
+        aug = sp.bmat([[self.S, sp.csr_matrix(V)], [sp.csr_matrix(W.T), sp.csr_matrix(C)]]).tocsc()
+        self.border = (m, spla.splu(aug))
+
+    def apply_inverse_bordered(self, x, T):
+        """CoarseSolver::ApplyInverse(X, T, Y, S) (:454-560): full augmented right-hand side, no Dirichlet zeroing."""
+        m, lu = self.border
+        sol = lu.solve(np.concatenate([x, T]))
+        return sol[:self.n], sol[self.n:]
 
     def apply_inverse(self, x):
         if self.n == 0:
@@ -237,13 +251,37 @@ class SchurPreconditioner:
         reduced = drop_by_value(reduced, SMALL, "RelDropDiag")
         self.reduced = reduced
         vs_gids = prec.map2[vs]
+        border = getattr(self, "border", None)
+        if border is not None:
+            # ComputeBorder (:631-664): transform V and W, their V-sum rows are the border of the next level
+            SV, SW, SC = border
+            self.bV = np.column_stack([self.apply_ot(SV[:, j]) for j in range(SV.shape[1])])
+            self.bW = np.column_stack([self.apply_ot(SW[:, j]) for j in range(SW.shape[1])])
         if prec.level + 1 < prec.max_level:
             next_tv = self.apply_ot(self.tv2)[vs]
             self.next = Preconditioner(reduced, prec.params.next_level(), level=prec.level + 1,
                                        gids=vs_gids, testvector=next_tv, ngid=prec.ngid)
+            if border is not None:
+                self.next.set_border(self.bV[vs], self.bW[vs], SC)
             self.next.compute()
         else:
             self.next = CoarseSolver(reduced, vs_gids, prec.params.fix_gids)
+            if border is not None:
+                self.next.set_border(self.bV[vs], self.bW[vs], SC)
+
+    def set_border(self, V, W, C):
+        self.border = (V, W, C)
+
+    def apply_inverse_bordered(self, x, T):
+        """bordered ApplyInverse (:1517-1617): block-diagonal solve, T - W'(M11 \ f1), bordered next level."""
+        B = self.apply_ot(x)
+        Y = np.zeros_like(B)
+        for ids, lu in self.blocks:
+            Y[ids] = sla.lu_solve(lu, B[ids])
+        vs = self.vsum_pos
+        Tc = T - self.bW.T @ Y
+        Y[vs], S = self.next.apply_inverse_bordered(B[vs], Tc)
+        return self.apply_ot(Y), S
 
     def apply_inverse(self, x):
         """ApplyInverse (:1010-1093)."""
@@ -311,6 +349,16 @@ class Preconditioner:
             else:
                 self.lu.append(None)
         tv2 = self.testvector[self.i2]  # CreateTestVector (:781-818)
+        sb = None
+        if getattr(self, "border", None) is not None:
+            # ComputeBorder (:519-588): border of the Schur complement system
+            V, W, C = self.border
+            V1, V2, W1, W2 = V[self.i1], V[self.i2], W[self.i1], W[self.i2]
+            self.W1 = W1
+            self.Q1 = np.column_stack([self.a11_inverse(V1[:, j]) for j in range(V.shape[1])])
+            SV = V2 - self.A21 @ self.Q1
+            SW = W2 - self.A12.T @ np.column_stack([self.a11_inverse(W1[:, j], trans=True) for j in range(W.shape[1])])
+            sb = (SV, SW, C - W1.T @ self.Q1)
         if self.level >= self.max_level:
             # Preconditioner.cpp:485-500: explicit SC, direct solve
             S = self.A22.tolil(copy=True).tocsr()
@@ -329,8 +377,12 @@ class Preconditioner:
                                       shape=S.shape)
             S = drop_by_value(S, SMALL, "RelZeroDiag")
             self.schur = CoarseSolver(S, self.map2, self.params.fix_gids)
+            if sb is not None:
+                self.schur.set_border(*sb)
         else:
             self.schur = SchurPreconditioner(self, tv2)
+            if sb is not None:
+                self.schur.set_border(*sb)
             self.schur.compute()
         self.computed = True
         return self
@@ -352,12 +404,37 @@ class Preconditioner:
         B = self.lu[sd].solve(A12)
         return -(A21 @ B)
 
-    def a11_inverse(self, b1):
+    def a11_inverse(self, b1, trans=False):
         x1 = np.empty_like(b1)
         for sd, lu in enumerate(self.lu):
             if lu is not None:
-                x1[self.loc1[sd]] = lu.solve(b1[self.loc1[sd]])
+                x1[self.loc1[sd]] = lu.solve(b1[self.loc1[sd]], trans="T" if trans else "N")
         return x1
+
+    def set_border(self, V, W=None, C=None):
+        """BorderedOperator::SetBorder (src/HYMLS_Preconditioner.cpp:844-918): [K V; W' C]; W defaults to V, C to 0.
+        Compute has to be called afterwards."""
+        V = np.asarray(V, dtype=float).reshape(self.A.shape[0], -1)
+        W = V if W is None else np.asarray(W, dtype=float).reshape(self.A.shape[0], -1)
+        m = V.shape[1]
+        C = np.zeros((m, m)) if C is None else np.asarray(C, dtype=float).reshape(m, m)
+        self.border = (V, W, C)
+        self.computed = False
+
+    def apply_inverse_bordered(self, b, T):
+        """ApplyInverse(B, T, X, S) (src/HYMLS_Preconditioner.cpp:930-1070 with the border branches)."""
+        if not self.computed:
+            raise RuntimeError("The preconditioner has not yet been computed.")
+        b = np.asarray(b, dtype=float)
+        x1 = self.a11_inverse(b[self.i1])
+        rhs2 = b[self.i2] - self.A21 @ x1
+        q = np.asarray(T, dtype=float) - self.W1.T @ x1
+        x2, S = self.schur.apply_inverse_bordered(rhs2, q)
+        x1 = x1 - self.a11_inverse(self.A12 @ x2) - self.Q1 @ S
+        x = np.zeros_like(b)
+        x[self.i1] = x1
+        x[self.i2] = x2
+        return x, S
 
     def apply_inverse(self, b):
         """Preconditioner::ApplyInverse (src/HYMLS_Preconditioner.cpp:930-1070)."""

@@ -410,6 +410,52 @@ void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* i
   }
 }
 
+double dot(int64_t n, const double* x, const double* y) {
+  double s = 0;
+  for (int64_t i = 0; i < n; i++) s += x[i] * y[i];
+  return s;
+}
+
+void solve_transposed(const PlanD& P, const BatchD& B, const int32_t* order, int32_t nfronts, int32_t, double* x) {
+  std::vector<double> a;
+  for (int b = 0; b < B.nb; b++) {
+    double* xb = x + B.xoff[b];
+    double* cb = B.contrib + (int64_t)b * P.contrib_size;
+    const double* fac = B.factor + (int64_t)b * P.factor_size;
+    auto linv = [&](const FrontD& F, const double* lp, int64_t i, int64_t k) { return P.packed ? lp[packed_lower(F.w, i, k)] : lp[i + (int64_t)(F.w + F.ri) * k]; };
+    auto uinv = [&](const FrontD& F, const double* lp, int64_t i, int64_t k) { return P.packed ? lp[packed_upper(F.w, F.ri, i, k)] : lp[i + (int64_t)(F.w + F.ri) * k]; };
+    auto pl = [&](const FrontD& F, const double* lp, int64_t j, int64_t k) { return P.packed ? lp[packed_l21(F.w, F.ri, j, k)] : lp[(F.w + j) + (int64_t)(F.w + F.ri) * k]; };
+    for (int q = 0; q < nfronts; q++) {
+      const FrontD& F = P.fronts[order[q]];
+      const int w = F.w, ri = F.ri;
+      const double* lp = fac + F.lp_off; const double* Q = fac + F.q_off;
+      a.assign(w + ri, 0.0);
+      for (int j = 0; j < w + ri; j++) {
+        double v = j < w ? xb[F.c0 + j] : 0.0;
+        for (int t = P.asm_ptr[F.a_off + j]; t < P.asm_ptr[F.a_off + j + 1]; t++) v += cb[P.asm_src[t]];
+        a[j] = v;
+      }
+      for (int i = 0; i < w; i++) { double s = 0; for (int k = 0; k <= i; k++) s += uinv(F, lp, k, i) * a[k]; xb[F.c0 + i] = s; }
+      for (int j = 0; j < ri; j++) { double s = 0; for (int k = 0; k < w; k++) s += Q[k + (int64_t)w * j] * a[k]; cb[F.c_off + j] = a[w + j] - s; }
+    }
+    for (int q = nfronts - 1; q >= 0; q--) {
+      const FrontD& F = P.fronts[order[q]];
+      const int w = F.w, ri = F.ri;
+      const double* lp = fac + F.lp_off;
+      a.assign(w + ri, 0.0);
+      for (int k = 0; k < w + ri; k++) a[k] = k < w ? xb[F.c0 + k] : xb[P.fidx[F.idx_off + k]];
+      std::vector<double> out(w);
+      for (int i = 0; i < w; i++) {
+        double s = a[i];
+        for (int k = i + 1; k < w; k++) s += linv(F, lp, k, i) * a[k];
+        for (int j = 0; j < ri; j++) s -= pl(F, lp, j, i) * a[w + j];
+        out[i] = s;
+      }
+      for (int i = 0; i < w; i++) xb[F.c0 + i] = out[i];
+    }
+  }
+}
+
 void dense_invert_all(int32_t nblk, const BlkD* blocks, int32_t, int32_t* flag) {
   for (int b = 0; b < nblk; b++) dense_invert(blocks[b].nb, 1, const_cast<double*>(blocks[b].binv), flag);
 }

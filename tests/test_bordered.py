@@ -1,0 +1,96 @@
+"""Bordered systems [K V; W' C] (HYMLS::BorderedOperator interface of the preconditioner).
+The exactness tests restate the reference's unit tests BorderedApplyInverse / BorderedApplyInverse_without_C
+(testSuite/unit_tests/HYMLS_Preconditioner.cpp:278-378: random V, W (n x 2), random or zero C, one-level
+preconditioner = exact bordered solve, 1e-10); the multi-level cases compare with the oracle."""
+import numpy as np
+import pytest
+
+import hymls_amd
+from common import problem, xml_params, rel_diff
+from oracle.partition import Params
+from oracle.hymls import Preconditioner as OraclePrec
+
+
+def bordered_exact(lib, with_c):
+    A, tv = problem("Laplace", 8)
+    N, m = A.shape[0], 2
+    rng = np.random.default_rng(41)
+    V, W = rng.uniform(-1, 1, (N, m)), rng.uniform(-1, 1, (N, m))
+    C = rng.uniform(-1, 1, (m, m)) if with_c else None
+    P = hymls_amd.Preconditioner(A, xml_params("Laplace", 8, 4, 0), testVector=tv, lib=lib)
+    assert P.Initialize() == 0
+    assert P.SetBorder(V, W, C) == 0 and P.HaveBorder() and not P.IsComputed()
+    assert P.Compute() == 0
+    x_ex, s_ex = rng.uniform(-1, 1, N), (rng.uniform(-1, 1, m) if with_c else np.zeros(m))
+    Cm = C if with_c else np.zeros((m, m))
+    b = A @ x_ex + V @ s_ex
+    t = W.T @ x_ex + Cm @ s_ex
+    x, s = P.ApplyInverseBordered(b, t)
+    assert np.abs(x - x_ex).max() < 1e-10 and np.abs(s - s_ex).max() < 1e-10
+    # plain ApplyInverse of a bordered operator: border right-hand side 0, S dropped
+    x0, _ = P.ApplyInverseBordered(b, np.zeros(m))
+    assert np.array_equal(P.ApplyInverse(b), x0)
+    # removing the border gives the plain preconditioner back
+    P.SetBorder(None)
+    P.Compute()
+    assert np.abs(P.ApplyInverse(A @ x_ex) - x_ex).max() < 1e-10
+
+
+CASES = [("Laplace", 16, 4, 1, -1, "Cartesian"), ("Stokes-C", 8, 4, 0, -1, "Skew Cartesian"),
+         ("Stokes-C", 16, 8, 1, -1, "Skew Cartesian"), ("Laplace", 16, 4, 2, 2, "Cartesian"),
+         ("Stokes-C", 16, 4, 2, 2, "Skew Cartesian")]
+
+
+def bordered_vs_oracle(lib, eq, n, sx, levels, cx, part, v_is_w=False):
+    A, tv = problem(eq, n)
+    N, m = A.shape[0], 2
+    rng = np.random.default_rng(42)
+    V = rng.uniform(-1, 1, (N, m))
+    W = V if v_is_w else rng.uniform(-1, 1, (N, m))
+    C = rng.uniform(-1, 1, (m, m))
+    O = OraclePrec(A, Params(nx=n, ny=n, nz=n, sx=sx, levels=levels, equations=eq, partitioner=part, cx=cx).finalize(), testvector=tv)
+    O.set_border(V, W, C)
+    O.compute()
+    P = hymls_amd.Preconditioner(A, xml_params(eq, n, sx, levels, cx, part), testVector=tv, lib=lib)
+    P.Initialize()
+    P.SetBorder(V, None if v_is_w else W, C)
+    P.Compute()
+    b, t = rng.uniform(-1, 1, N), rng.uniform(-1, 1, m)
+    xo, so = O.apply_inverse_bordered(b, t)
+    xp, sp = P.ApplyInverseBordered(b, t)
+    assert rel_diff(xp, xo) < 1e-9 and rel_diff(sp, so) < 1e-8
+    # SetMatrix with the same pattern + Compute keeps the border (reference: computed_ = false, border stays)
+    P.SetMatrix(A * 2.0)
+    P.Compute()
+    O2 = OraclePrec(A * 2.0, O.params, testvector=tv)
+    O2.set_border(V, W, C)
+    O2.compute()
+    xo2, so2 = O2.apply_inverse_bordered(b, t)
+    xp2, sp2 = P.ApplyInverseBordered(b, t)
+    assert rel_diff(xp2, xo2) < 1e-9 and rel_diff(sp2, so2) < 1e-8
+
+
+@pytest.mark.parametrize("with_c", [True, False])
+def test_bordered_exact_hostsim(hostsim_lib, with_c):
+    bordered_exact(hostsim_lib, with_c)
+
+
+@pytest.mark.parametrize("eq,n,sx,levels,cx,part", CASES)
+def test_bordered_vs_oracle_hostsim(hostsim_lib, eq, n, sx, levels, cx, part):
+    bordered_vs_oracle(hostsim_lib, eq, n, sx, levels, cx, part)
+
+
+def test_bordered_w_defaults_to_v_hostsim(hostsim_lib):
+    bordered_vs_oracle(hostsim_lib, "Stokes-C", 16, 8, 1, -1, "Skew Cartesian", v_is_w=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_c", [True, False])
+def test_bordered_exact_gpu(gpu_lib, with_c):
+    bordered_exact(gpu_lib, with_c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,sx,levels,cx,part", CASES)
+def test_bordered_vs_oracle_gpu(gpu_lib, eq, n, sx, levels, cx, part):
+    bordered_vs_oracle(gpu_lib, eq, n, sx, levels, cx, part)

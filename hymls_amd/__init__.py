@@ -10,7 +10,7 @@ HIP library is missing, importing :class:`Preconditioner` users get a loud error
 from .api import (Preconditioner, HymlsError, load_library, generate_matrix, generate_testvector, generate_rows,
                   generate_testvector_rows, LIB_PATH)
 
-from .solver import Solver
+from .solver import Solver, BorderedSolver
 
-__all__ = ["Solver", "Preconditioner", "HymlsError", "load_library", "generate_matrix", "generate_testvector", "generate_rows",
+__all__ = ["Solver", "BorderedSolver", "Preconditioner", "HymlsError", "load_library", "generate_matrix", "generate_testvector", "generate_rows",
            "generate_testvector_rows", "LIB_PATH"]

@@ -177,3 +177,61 @@ class Solver:
             p = z + (rz_new / rz) * p
             rz = rz_new
         return x, its, rel
+
+
+class BorderedSolver(Solver):
+    """Krylov solve of the bordered system [K V; W' C] [x; s] = [b; t] with the bordered preconditioner
+    (the reference's HYMLS::BorderedSolver, src/HYMLS_BorderedSolver.hpp/.cpp: the Krylov vectors are the
+    augmented vectors [x; s], the operator applies the border explicitly, the preconditioner solves its own
+    bordered system level by level).  One GPU."""
+
+    def __init__(self, K, precond, params=None):
+        super().__init__(K, precond, params)
+        self._K, self._P = K, precond
+        self._V = self._W = self._C = None
+
+    def SetBorder(self, V, W=None, C=None, device=None):
+        """also sets the border of the preconditioner; call precond.Compute() afterwards (as in the reference)"""
+        if V is None:
+            self._V = self._W = self._C = None
+            self._P.SetBorder(None)
+            return 0
+        V = np.asarray(V, dtype=np.float64).reshape(V.shape[0], -1)
+        W = V if W is None else np.asarray(W, dtype=np.float64).reshape(V.shape)
+        m = V.shape[1]
+        C = np.zeros((m, m)) if C is None else np.asarray(C, dtype=np.float64).reshape(m, m)
+        self._P.SetBorder(V, W, C)
+        self._V = torch.from_numpy(np.ascontiguousarray(V)).to(device) if device else torch.from_numpy(np.ascontiguousarray(V))
+        self._W = torch.from_numpy(np.ascontiguousarray(W)).to(self._V.device)
+        self._C = torch.from_numpy(np.ascontiguousarray(C)).to(self._V.device)
+        return 0
+
+    def ApplyInverse(self, B, T=None, X=None):
+        """returns (X, S); B: device tensor (n,), T: array-like (m,) (default 0)"""
+        if self._V is None:
+            return super().ApplyInverse(B, X), np.zeros(0)
+        n, m = B.numel(), self._V.shape[1]
+        if self._V.device != B.device:
+            self._V, self._W, self._C = self._V.to(B.device), self._W.to(B.device), self._C.to(B.device)
+        t = torch.zeros(m, dtype=B.dtype, device=B.device) if T is None else torch.as_tensor(np.asarray(T, dtype=np.float64)).to(B.device)
+        kmv, papply = self._K.MatVec if hasattr(self._K, "MatVec") else self._K, self._P.ApplyInverseBordered
+
+        def matvec(z):
+            y = torch.empty_like(z)
+            y[:n] = kmv(z[:n].contiguous()) + self._V @ z[n:]
+            y[n:] = self._W.t() @ z[:n] + self._C @ z[n:]
+            return y
+
+        def prec(z):
+            x, s = papply(z[:n].contiguous(), z[n:].cpu().numpy())
+            return torch.cat([x, torch.from_numpy(s).to(z.device)])
+
+        saved = (self._matvec, self._prec)
+        self._matvec, self._prec = matvec, prec
+        try:
+            z = super().ApplyInverse(torch.cat([B, t]))
+        finally:
+            self._matvec, self._prec = saved
+        if X is not None:
+            X.copy_(z[:n])
+        return z[:n].clone(), z[n:].cpu().numpy()

@@ -94,3 +94,47 @@ def test_bordered_exact_gpu(gpu_lib, with_c):
 @pytest.mark.parametrize("eq,n,sx,levels,cx,part", CASES)
 def test_bordered_vs_oracle_gpu(gpu_lib, eq, n, sx, levels, cx, part):
     bordered_vs_oracle(gpu_lib, eq, n, sx, levels, cx, part)
+
+
+def bordered_krylov(lib, dev):
+    """BorderedSolver: GMRES on the augmented vectors with the bordered multi-level preconditioner converges to the
+    solution of [K V; W' C] [x; s] = [b; t] in as many iterations as the same loop with the oracle's operator."""
+    import torch
+    from oracle import krylov
+    eq, n, sx, levels, part = "Stokes-C", 16, 8, 1, "Skew Cartesian"
+    A, tv = problem(eq, n)
+    N, m = A.shape[0], 2
+    rng = np.random.default_rng(43)
+    V, W, C = rng.uniform(-1, 1, (N, m)), rng.uniform(-1, 1, (N, m)), rng.uniform(-1, 1, (m, m))
+    P = hymls_amd.Preconditioner(A, xml_params(eq, n, sx, levels, -1, part), testVector=tv, lib=lib)
+    P.Initialize()
+    S = hymls_amd.BorderedSolver(P, P, {"Krylov Method": "GMRES", "Iterative Solver": {"Convergence Tolerance": 1e-8, "Maximum Iterations": 300, "Num Blocks": 300}})
+    S.SetBorder(V, W, C, device=dev)
+    P.Compute()
+    x_ex, s_ex = rng.uniform(-1, 1, N), rng.uniform(-1, 1, m)
+    b, t = A @ x_ex + V @ s_ex, W.T @ x_ex + C @ s_ex
+    x, s = S.ApplyInverse(torch.from_numpy(b).to(dev), t)
+    x = x.cpu().numpy()
+    assert np.linalg.norm(A @ x + V @ s - b) <= 1e-7 * np.linalg.norm(b) and np.abs(W.T @ x + C @ s - t).max() < 1e-6
+    O = OraclePrec(A, Params(nx=n, ny=n, nz=n, sx=sx, levels=levels, equations=eq, partitioner=part).finalize(), testvector=tv)
+    O.set_border(V, W, C)
+    O.compute()
+
+    def op(z):
+        return np.concatenate([A @ z[:N] + V @ z[N:], W.T @ z[:N] + C @ z[N:]])
+
+    def pr(z):
+        xx, ss = O.apply_inverse_bordered(z[:N], z[N:])
+        return np.concatenate([xx, ss])
+
+    _, its_o, _ = krylov.gmres(op, np.concatenate([b, t]), pr, tol=1e-8, maxit=300)
+    assert abs(S.getNumIter() - its_o) <= 1
+
+
+def test_bordered_krylov_hostsim(hostsim_lib):
+    bordered_krylov(hostsim_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_bordered_krylov_gpu(gpu_lib):
+    bordered_krylov(gpu_lib, "cuda")

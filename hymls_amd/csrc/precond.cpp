@@ -234,7 +234,7 @@ int32_t BatchedLU::check_flag() const {
 
 // ------------------------------------------------------------------ DirectSolver
 DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids, int64_t ngid,
-                           const Params& cp, const ivec* clu_ptr, const ivec* clu, const ivec* clu_coord) {
+                           const Params& cp, const ivec* clu_ptr, const ivec* clu, const ivec* clu_coord, bool border_pending) {
   // CoarseSolver::Compute (reference src/HYMLS_CoarseSolver.cpp:131-152)
   Csr A = drop_by_value(A0, SMALL_ENTRY, 2);
   n_ = A.n;
@@ -249,6 +249,23 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
         else if (A.col[e] == lid) A.val[e] = 0.0;
       }
     fix_lids_.push_back(lid);
+  }
+  if (border_pending && fix_gids.empty() && n_ > 0) {
+    // the last pressure node (if the problem has pressures) joins the border: its row and column are kept aside and
+    // replaced by a Dirichlet row in the matrix that is factored
+    int z = -1;
+    for (int i = n_ - 1; i >= 0 && z < 0; i--) if (cp.vtype[gids[i] % cp.dof] == VT_P) z = i;
+    if (z >= 0) {
+      tail_z_ = z;
+      tail_col_.assign(n_, 0.0); tail_row_.assign(n_, 0.0);
+      for (int i = 0; i < n_; i++)
+        for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++) {
+          const int c = A.col[e];
+          if (i == z && c == z) { tail_d_ = A.val[e]; A.val[e] = 1.0; }
+          else if (i == z) { tail_row_[c] = A.val[e]; A.val[e] = 0.0; }
+          else if (c == z) { tail_col_[i] = A.val[e]; A.val[e] = 0.0; }
+        }
+    }
   }
   if (n_ == 0) return;
   LocalPattern lp;
@@ -312,39 +329,76 @@ void DirectSolver::set_border(int m, const double* dV, const double* dW, const d
   bm_ = 0; bMinv_.clear();
   if (m <= 0 || n_ == 0) return;
   bm_ = m;
-  d_bZ_ = (double*)dev::alloc((size_t)n_ * m * sizeof(double));
-  d_bW_ = (double*)dev::alloc((size_t)n_ * m * sizeof(double));
-  dev::d2d(d_bW_, dW, (size_t)n_ * m * sizeof(double));
-  for (int j = 0; j < m; j++) solve(dV + (size_t)j * n_, d_bZ_ + (size_t)j * n_, false);
-  // M = C - W' Z (m x m, column-major), inverted on the host with partial pivoting
-  dvec M((size_t)m * m);
+  const int tl = tail_z_ >= 0 ? 1 : 0, mt = m + tl;
+  const size_t n = (size_t)n_;
+  // border columns [tail column | V], border rows [tail row | W]; entries at the tail node go to the small block D
+  dvec D((size_t)mt * mt, 0.0);
+  d_bZ_ = (double*)dev::alloc(n * mt * sizeof(double));
+  d_bW_ = (double*)dev::alloc(n * mt * sizeof(double));
+  double* d_U = (double*)dev::alloc(n * mt * sizeof(double));
+  if (tl) {
+    dev::h2d(d_U, tail_col_.data(), n * sizeof(double));
+    dev::h2d(d_bW_, tail_row_.data(), n * sizeof(double));
+    D[0] = tail_d_;
+  }
+  dev::d2d(d_U + n * tl, dV, n * m * sizeof(double));
+  dev::d2d(d_bW_ + n * tl, dW, n * m * sizeof(double));
   for (int j = 0; j < m; j++)
-    for (int i = 0; i < m; i++) M[i + (size_t)m * j] = C[i + (size_t)m * j] - dev::dot(n_, d_bW_ + (size_t)i * n_, d_bZ_ + (size_t)j * n_);
-  bMinv_.assign((size_t)m * m, 0.0);
-  for (int i = 0; i < m; i++) bMinv_[i + (size_t)m * i] = 1.0;
-  for (int k = 0; k < m; k++) {
+    for (int i = 0; i < m; i++) D[(i + tl) + (size_t)mt * (j + tl)] = C[i + (size_t)m * j];
+  if (tl) {
+    const double zero = 0.0;
+    for (int j = 0; j < m; j++) {
+      dev::d2h(&D[0 + (size_t)mt * (j + 1)], d_U + n * (j + 1) + tail_z_, sizeof(double));      // V[z, j]
+      dev::d2h(&D[(j + 1) + (size_t)mt * 0], d_bW_ + n * (j + 1) + tail_z_, sizeof(double));    // W[z, j]
+      dev::h2d(d_U + n * (j + 1) + tail_z_, &zero, sizeof(double));
+      dev::h2d(d_bW_ + n * (j + 1) + tail_z_, &zero, sizeof(double));
+    }
+  }
+  for (int j = 0; j < mt; j++) solve(d_U + n * j, d_bZ_ + n * j, false);                  // Z = A^{-1} U
+  dev::free(d_U);
+  // M = D - W' Z, inverted on the host with partial pivoting
+  dvec M = D;
+  for (int j = 0; j < mt; j++)
+    for (int i = 0; i < mt; i++) M[i + (size_t)mt * j] -= dev::dot(n_, d_bW_ + n * i, d_bZ_ + n * j);
+  bMinv_.assign((size_t)mt * mt, 0.0);
+  for (int i = 0; i < mt; i++) bMinv_[i + (size_t)mt * i] = 1.0;
+  for (int k = 0; k < mt; k++) {
     int p = k;
-    for (int i = k + 1; i < m; i++) if (std::abs(M[i + (size_t)m * k]) > std::abs(M[p + (size_t)m * k])) p = i;
-    HYMLS_CHECK(M[p + (size_t)m * k] != 0.0 && std::isfinite(M[p + (size_t)m * k]), -4, "singular bordered coarse system");
-    if (p != k) for (int j = 0; j < m; j++) { std::swap(M[k + (size_t)m * j], M[p + (size_t)m * j]); std::swap(bMinv_[k + (size_t)m * j], bMinv_[p + (size_t)m * j]); }
-    const double ip = 1.0 / M[k + (size_t)m * k];
-    for (int j = 0; j < m; j++) { M[k + (size_t)m * j] *= ip; bMinv_[k + (size_t)m * j] *= ip; }
-    for (int i = 0; i < m; i++) {
+    for (int i = k + 1; i < mt; i++) if (std::abs(M[i + (size_t)mt * k]) > std::abs(M[p + (size_t)mt * k])) p = i;
+    HYMLS_CHECK(M[p + (size_t)mt * k] != 0.0 && std::isfinite(M[p + (size_t)mt * k]), -4, "singular bordered coarse system");
+    if (p != k) for (int j = 0; j < mt; j++) { std::swap(M[k + (size_t)mt * j], M[p + (size_t)mt * j]); std::swap(bMinv_[k + (size_t)mt * j], bMinv_[p + (size_t)mt * j]); }
+    const double ip = 1.0 / M[k + (size_t)mt * k];
+    for (int j = 0; j < mt; j++) { M[k + (size_t)mt * j] *= ip; bMinv_[k + (size_t)mt * j] *= ip; }
+    for (int i = 0; i < mt; i++) {
       if (i == k) continue;
-      const double f = M[i + (size_t)m * k];
+      const double f = M[i + (size_t)mt * k];
       if (f == 0.0) continue;
-      for (int j = 0; j < m; j++) { M[i + (size_t)m * j] -= f * M[k + (size_t)m * j]; bMinv_[i + (size_t)m * j] -= f * bMinv_[k + (size_t)m * j]; }
+      for (int j = 0; j < mt; j++) { M[i + (size_t)mt * j] -= f * M[k + (size_t)mt * j]; bMinv_[i + (size_t)mt * j] -= f * bMinv_[k + (size_t)mt * j]; }
     }
   }
 }
 
 void DirectSolver::apply_inverse_bordered(const double* b, const double* T, double* x, double* S) {
   if (bm_ == 0) { apply_inverse(b, x); return; }
-  solve(b, x, false);                       // (the augmented system of the reference does not zero the fixed rows)
-  dvec r(bm_);
-  for (int i = 0; i < bm_; i++) r[i] = T[i] - dev::dot(n_, d_bW_ + (size_t)i * n_, x);
-  for (int i = 0; i < bm_; i++) { S[i] = 0.0; for (int j = 0; j < bm_; j++) S[i] += bMinv_[i + (size_t)bm_ * j] * r[j]; }
-  for (int j = 0; j < bm_; j++) dev::axpby(n_, -S[j], d_bZ_ + (size_t)j * n_, 1.0, x);
+  const int tl = tail_z_ >= 0 ? 1 : 0, mt = bm_ + tl;
+  const size_t n = (size_t)n_;
+  dvec r(mt), y(mt);
+  if (tl) {
+    // the equation of the tail node belongs to the border: its right-hand side entry moves there
+    dev::d2h(&r[0], b + tail_z_, sizeof(double));
+    dev::d2d(x, b, n * sizeof(double));          // (x doubles as the modified right-hand side)
+    const double zero = 0.0;
+    dev::h2d(x + tail_z_, &zero, sizeof(double));
+    solve(x, x, false);
+  } else {
+    solve(b, x, false);                           // (the augmented system of the reference does not zero the fixed rows)
+  }
+  for (int i = 0; i < bm_; i++) r[i + tl] = T[i];
+  for (int i = 0; i < mt; i++) r[i] -= dev::dot(n_, d_bW_ + n * i, x);
+  for (int i = 0; i < mt; i++) { y[i] = 0.0; for (int j = 0; j < mt; j++) y[i] += bMinv_[i + (size_t)mt * j] * r[j]; }
+  for (int j = 0; j < mt; j++) dev::axpby(n_, -y[j], d_bZ_ + n * j, 1.0, x);
+  if (tl) dev::h2d(x + tail_z_, &y[0], sizeof(double));
+  for (int i = 0; i < bm_; i++) S[i] = y[i + tl];
 }
 
 void DirectSolver::add_stats(ApplyStats& st, bool) const {
@@ -1359,7 +1413,7 @@ void LevelSolver::compute() {
     next_level_ = nullptr;
     next_is_direct_ = true;
     if (dist) next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_));
-    else next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &sep_sd_ptr_, &sep_sd_, &sd_center_));
+    else next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &sep_sd_ptr_, &sep_sd_, &sd_center_, bm_ > 0));
     build_handoff(next_gids);
     set_next_border();
     return;
@@ -1421,7 +1475,7 @@ void LevelSolver::compute() {
         for (int t = sep_sd_ptr_[vs_[g]]; t < sep_sd_ptr_[vs_[g] + 1]; t++) cl.push_back(sep_sd_[t]);
         cp.push_back((int32_t)cl.size());
       }
-      next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &cp, &cl, &sd_center_));
+      next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &cp, &cl, &sd_center_, bm_ > 0));
     }
     build_handoff(next_gids);
     set_next_border();

@@ -66,8 +66,12 @@ class Operator {  // something with ApplyInverse on device vectors in its own ro
 class DirectSolver : public Operator {
  public:
   // clu_ptr/clu/clu_coord: optional clusters of the rows (see LocalPattern::clu)
+  // border_pending: a border will be set (set_border) before the first solve.  If no Dirichlet node is configured the
+  // matrix may be singular with its null space only fixed by the border (Stokes without "Fix Pressure Level"): then one
+  // pressure row/column is moved into the border ("tail") and the remaining nonsingular matrix is factored.
   DirectSolver(const Csr& A, const ivec& gids, const ivec& fix_gids, int64_t ngid, const Params& coord_params,
-               const ivec* clu_ptr = nullptr, const ivec* clu = nullptr, const ivec* clu_coord = nullptr);
+               const ivec* clu_ptr = nullptr, const ivec* clu = nullptr, const ivec* clu_coord = nullptr,
+               bool border_pending = false);
   ~DirectSolver() override;
   void apply_inverse(const double* b, double* x) override;
   void set_border(int m, const double* dV, const double* dW, const double* C) override;
@@ -82,6 +86,10 @@ class DirectSolver : public Operator {
   int bm_ = 0;
   double *d_bZ_ = nullptr, *d_bW_ = nullptr;
   dvec bMinv_;
+  // tail: row/column tail_z_ of the matrix lives in the border (see the constructor)
+  int32_t tail_z_ = -1;
+  dvec tail_col_, tail_row_;
+  double tail_d_ = 0.0;
   std::unique_ptr<BatchedLU> lu_;
   double* d_val_ = nullptr;
   double* d_z_ = nullptr;

@@ -138,3 +138,43 @@ def test_bordered_krylov_hostsim(hostsim_lib):
 @pytest.mark.gpu
 def test_bordered_krylov_gpu(gpu_lib):
     bordered_krylov(gpu_lib, "cuda")
+
+
+def singular_with_border(lib, levels, cx):
+    """Stokes without "Fix Pressure Level": K is singular (constant pressure mode), the border [K v; v' 0] with v the
+    constant-pressure vector makes the system regular (what testSuite/cavity.xml asks for with "Null Space Type" =
+    "Constant P").  The oracle factors the AugmentedMatrix of the coarsest level with pivoting (as the reference's KLU);
+    the product moves one pressure node of the coarse matrix into the border instead."""
+    from dataclasses import replace
+    eq, n, sx, part = "Stokes-C", 16, 4 if levels == 2 else 8, "Skew Cartesian"
+    A, tv = problem(eq, n)
+    N = A.shape[0]
+    v = np.zeros((N, 1)); v[3::4, 0] = 1.0
+    assert np.abs(A @ v).max() < 1e-9                     # v spans the null space
+    op = Params(nx=n, ny=n, nz=n, sx=sx, levels=levels, equations=eq, partitioner=part, cx=cx).finalize()
+    op = replace(op, fix_gids=[])
+    O = OraclePrec(A, op, testvector=tv)
+    O.set_border(v, v, np.zeros((1, 1)))
+    O.compute()
+    prm = xml_params(eq, n, sx, levels, cx, part, extra={"Fix Pressure Level": False})
+    P = hymls_amd.Preconditioner(A, prm, testVector=tv, lib=lib)
+    P.Initialize()
+    P.SetBorder(v)
+    P.Compute()
+    rng = np.random.default_rng(44)
+    b, t = rng.uniform(-1, 1, N), rng.uniform(-1, 1, 1)
+    xo, so = O.apply_inverse_bordered(b, t)
+    xp, sp = P.ApplyInverseBordered(b, t)
+    assert np.isfinite(xp).all()
+    assert rel_diff(xp, xo) < 1e-8 and abs(sp[0] - so[0]) <= 1e-8 * max(1.0, abs(so[0]))
+
+
+@pytest.mark.parametrize("levels,cx", [(0, -1), (1, -1), (2, 2)])
+def test_singular_matrix_regular_bordered_hostsim(hostsim_lib, levels, cx):
+    singular_with_border(hostsim_lib, levels, cx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels,cx", [(1, -1), (2, 2)])
+def test_singular_matrix_regular_bordered_gpu(gpu_lib, levels, cx):
+    singular_with_border(gpu_lib, levels, cx)

@@ -11,7 +11,9 @@ hymls_amd.Preconditioner and hymls_amd.Solver, so that the reference's own examp
   MainUtils.cpp:260-348), "Number of factorizations", "Number of solves", "RHS Available",
   "Exact Solution Available",
 * "Problem", "Preconditioner", "Solver" sublists go to the operator classes unchanged.
-Not supported (as in the library): "Null Space Type" deflation / bordering, eigenvalue runs.
+* "Null Space Type" = "Constant P" (testSuite/cavity.xml): the constant-pressure vector becomes the border of the
+  system and of the preconditioner (hymls_amd.BorderedSolver), so that "Fix Pressure Level" = false works.
+Not supported: "Null Space Type" = "File", deflation of further vectors, eigenvalue runs.
 """
 import os
 import re
@@ -121,7 +123,16 @@ def run(xml_file, *overlays, lib=None, device=None, out=sys.stdout):
     P = hymls_amd.Preconditioner(K, params, testVector=tv, lib=lib)
     P.Initialize()
     res["initialize_s"] = time.time() - t0
-    S = hymls_amd.Solver(P, P, params)
+    null_space = drv.get("Null Space Type", "None")
+    if null_space == "Constant P":
+        dof = prob.get("Degrees of Freedom", dim + 1)
+        v = np.zeros((n, 1)); v[dof - 1::dof, 0] = 1.0
+        S = hymls_amd.BorderedSolver(P, P, params)
+        S.SetBorder(v, device=device)
+    elif null_space == "None":
+        S = hymls_amd.Solver(P, P, params)
+    else:
+        raise ValueError("Null Space Type '%s' is not supported" % null_space)
     rng = np.random.default_rng(drv.get("Random Seed", 1234) if drv.get("Random Seed", -1) != -1 else 1234)
     for f in range(drv.get("Number of factorizations", 1)):
         if f > 0 and drv.get("Diagonal Perturbation", 0.0) != 0.0:
@@ -140,6 +151,8 @@ def run(xml_file, *overlays, lib=None, device=None, out=sys.stdout):
                 b = P.MatVec(torch.from_numpy(np.ascontiguousarray(x_ex)).to(device)).clone()
             t0 = time.time()
             x = S.ApplyInverse(b)
+            if isinstance(x, tuple):        # bordered: (X, S)
+                x = x[0]
             t_solve = time.time() - t0
             r = float((b - P.MatVec(x)).norm() / b.norm())
             rec = {"iterations": S.getNumIter(), "residual": r, "solve_s": t_solve}

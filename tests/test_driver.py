@@ -41,6 +41,16 @@ XML = """<ParameterList name="Trilinos HYMLS">
 </ParameterList>
 """
 
+NULLSPACE = """<ParameterList name="Trilinos HYMLS">
+  <ParameterList name="Driver">
+    <Parameter name="Null Space Type" type="string" value="Constant P"/>
+  </ParameterList>
+  <ParameterList name="Preconditioner">
+    <Parameter name="Fix Pressure Level" type="bool" value="false"/>
+  </ParameterList>
+</ParameterList>
+"""
+
 OVERLAY = """<ParameterList name="Trilinos HYMLS">
   <ParameterList name="Preconditioner">
     <Parameter name="Number of Levels" type="int" value="2"/>
@@ -67,6 +77,7 @@ def _write_case(tmp_path, re):
     xml.write_text(XML % str(d))
     ov = tmp_path / "levels2.xml"
     ov.write_text(OVERLAY)
+    (tmp_path / "nullspace.xml").write_text(NULLSPACE)
     return str(xml), str(ov)
 
 
@@ -82,6 +93,9 @@ def check(tmp_path, lib, device):
     assert [l[1] for l in res["levels"]] == [3072, 435]
     res2 = driver.run(xml, ov, lib=lib, device=device)          # overlay file: one more level
     assert [l[1] for l in res2["levels"]] == [3072, 435, 15] and res2["solves"][0]["error"] < 1e-7
+    # the settings of the reference's cavity.xml: no pressure fix, the constant-pressure null space is a border
+    res3 = driver.run(xml, os.path.join(os.path.dirname(xml), "nullspace.xml"), lib=lib, device=device)
+    assert res3["solves"][0]["iterations"] <= 130 and res3["solves"][0]["error"] < 1e-6
 
 
 def test_driver_hostsim(tmp_path, hostsim_lib):

@@ -158,7 +158,18 @@ struct FusedSub {
   int32_t cls;         // index into the PlanD table
 };
 constexpr int FUSED_MAX_ITEMS = 2048;  // max work items (rows) of one tree level handled by the fused kernel
-void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, double* x);
+// optional fusion of the neighbouring vector kernels into the load / store of the fused solve:
+//   in  = 0: right-hand side = x (in place)      1: x_rhs[i] = b[perm[i]] (the entry gather of ApplyInverse)
+//         2: x_rhs[i] = (A x2)[i], A in CSR over the interior rows (y1 = A12 x2 of the second solve)
+//   out = 0: x[i] = solution                     1: user[perm[i]] = z[i] - solution (x1 -= A11 \ y1 and the exit scatter)
+struct FusedIO {
+  int32_t in = 0, out = 0;
+  const double* b = nullptr; const int32_t* perm = nullptr;
+  const int32_t* a_row = nullptr; const int32_t* a_col = nullptr; const double* a_val = nullptr; const double* x2 = nullptr;
+  const double* z = nullptr; double* user = nullptr;
+};
+void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, double* x,
+                          const FusedIO* io = nullptr);
 
 // ---- merged level-synchronous solve of the classes that do not fit the fused kernel (large subdomains
 // of the coarser levels): ONE launch per tree level and sweep covers every (class, member, front) of that

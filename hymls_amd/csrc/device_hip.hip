@@ -1351,7 +1351,7 @@ __device__ inline const double* uside(const double* base, int packed, int i, int
 }
 template <bool PROF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
-                                                         double* __restrict__ x, long long* __restrict__ prof) {
+                                                         double* __restrict__ x, long long* __restrict__ prof, FusedIO io) {
   extern __shared__ double lds[];
   long long tp[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, tstart = 0;
   auto tick = [&](int bucket) { if (PROF) { const long long t = wall_clock64(); tp[bucket] += t - t0; t0 = t; } };
@@ -1373,7 +1373,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     LF[i] = f;
   }
   double* xg = x + S.xoff;
-  for (int i = tid; i < P.nI; i += 256) X[i] = xg[i];
+  if (io.in == 0) {
+    for (int i = tid; i < P.nI; i += 256) X[i] = xg[i];
+  } else if (io.in == 1) {
+    for (int i = tid; i < P.nI; i += 256) X[i] = io.b[io.perm[S.xoff + i]];
+  } else {
+    for (int i = tid; i < P.nI; i += 256) {
+      double v = 0.0;
+      for (int e = io.a_row[S.xoff + i]; e < io.a_row[S.xoff + i + 1]; e++) v += io.a_val[e] * io.x2[io.a_col[e]];
+      X[i] = v;
+    }
+  }
   __syncthreads();
   tick(0);
   const double* __restrict__ fac = S.fac;
@@ -1538,7 +1548,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     __syncthreads();
     tick(ni > 128 ? 3 : 4);
   }
-  for (int i = tid; i < P.nI; i += 256) xg[i] = X[i];
+  if (io.out == 0) {
+    for (int i = tid; i < P.nI; i += 256) xg[i] = X[i];
+  } else {
+    for (int i = tid; i < P.nI; i += 256) io.user[io.perm[S.xoff + i]] = io.z[S.xoff + i] - X[i];
+  }
   if (PROF && tid == 0) {
     tp[5] = wall_clock64() - tstart;
     for (int q = 0; q < 6; q++) prof[(int64_t)blockIdx.x * 8 + q] = tp[q];
@@ -1547,14 +1561,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   }
 }
 
-void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, double* x) {
+void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, double* x, const FusedIO* iop) {
+  const FusedIO io = iop ? *iop : FusedIO();
   if (nsub <= 0) return;
   const size_t shm = (size_t)lds_doubles * sizeof(double);
   if (std::getenv("HYMLS_MI_FUSED_PROF")) {
     // development aid: per-phase wall-clock ticks (100 MHz) of every workgroup, averaged, on stderr
     long long* dprof = (long long*)alloc((size_t)nsub * 8 * sizeof(long long));
     if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(k_interior_fused<true>, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, dprof);
+    hipLaunchKernelGGL(k_interior_fused<true>, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, dprof, io);
     launch_check();
     std::vector<long long> h((size_t)nsub * 8);
     d2h(h.data(), dprof, h.size() * sizeof(long long));
@@ -1567,26 +1582,27 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
     return;
   }
   if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(k_interior_fused<false>, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, (long long*)nullptr);
+  hipLaunchKernelGGL(k_interior_fused<false>, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, (long long*)nullptr, io);
   launch_check();
 }
 
 // ------------------------------------------------------------------ separator-side kernels
-// one wave per group: dot product by shuffle reduction, then the axpy
+// eight lanes per group (the groups have 8 nodes on average; consecutive groups are contiguous, so a wave still
+// reads one contiguous stretch): dot product by shuffle reduction inside the 8 lanes, then the axpy
 __global__ void __launch_bounds__(256) k_ot(int32_t ng, const int32_t* __restrict__ gptr, const double* __restrict__ w, double* __restrict__ x) {
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (g >= ng) return;
-  const int b = gptr[g], e = gptr[g + 1];
+  const int g = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int lane = threadIdx.x & 7;
+  const bool on = g < ng;
+  const int b = on ? gptr[g] : 0, e = on ? gptr[g + 1] : 0;
   double s = 0.0;
-  for (int i = b + lane; i < e; i += 64) s += w[i] * x[i];
+  for (int i = b + lane; i < e; i += 8) s += w[i] * x[i];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  for (int i = b + lane; i < e; i += 64) x[i] = 2.0 * w[i] * s - x[i];
+  for (int off = 4; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  for (int i = b + lane; i < e; i += 8) x[i] = 2.0 * w[i] * s - x[i];
 }
 void ot_apply(int32_t ng, const int32_t* gptr, const double* w, double* x) {
   if (ng <= 0) return;
-  hipLaunchKernelGGL(k_ot, dim3((ng + 3) / 4), dim3(256), 0, g_stream, ng, gptr, w, x); launch_check();
+  hipLaunchKernelGGL(k_ot, dim3((ng + 31) / 32), dim3(256), 0, g_stream, ng, gptr, w, x); launch_check();
 }
 
 // Householder data of one group from the test vector slice (reference Householder::Apply):

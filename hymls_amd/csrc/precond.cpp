@@ -1529,11 +1529,21 @@ void LevelSolver::apply_inverse(const double* b, double* x) {
   // Preconditioner::ApplyInverse (reference src/HYMLS_Preconditioner.cpp:930-1070)
   double* z1 = d_z_;                    // [x1 | x1 of the neighbours next to my separators | x2]
   double* z2 = d_z_ + n1_ + ngi_;
+  // optional (HYMLS_MI_IO_FUSION=1; every subdomain in the fused kernel): the entry gather, y1 = A12 x2, x1 -= ... and
+  // the exit scatter of the interior part ride on the load / store of the two interior solves.  Measured neutral at 256^3
+  // (29.19 vs 29.35 ms: the scattered accesses cost the fused kernel what the separate kernels took), hence off by default.
+  const bool io_fused = n_fsubs_ > 0 && n_lsubs_ == 0 && (int64_t)n_fsubs_ == (int64_t)my_sds_.size() &&
+                        std::getenv("HYMLS_MI_IO_FUSION") != nullptr;
   if (profiling) dev::mark(0, true);
-  dev::gather(n1_, d_inperm_, b, z1);                       // b1
+  if (!io_fused) dev::gather(n1_, d_inperm_, b, z1);        // b1
   dev::gather(n2_, d_inperm_ + n1_, b, z2);                 // b2
   if (profiling) dev::mark(1, true);
-  interior_solve(z1);                                       // x1 = A11 \ b1
+  if (io_fused) {
+    dev::FusedIO io; io.in = 1; io.b = b; io.perm = d_inperm_;
+    dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, z1, &io);
+  } else {
+    interior_solve(z1);                                     // x1 = A11 \ b1
+  }
   if (profiling) { dev::mark(1, false); dev::mark(2, true); }
   xch_int_.forward(z1, z1);                                 // halo: interior layer of the neighbouring ranks
   dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1, z2, -1.0, 1.0);  // b2 - A21 x1
@@ -1541,12 +1551,20 @@ void LevelSolver::apply_inverse(const double* b, double* x) {
   schur_apply(z2, d_t2_);                                   // x2
   if (profiling) { dev::mark(3, false); dev::mark(2, true); }
   xch_sep_.forward(d_t2_, d_t2_);                           // halo: separators owned by the neighbouring ranks
-  dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0);  // y1 = A12 x2
-  if (profiling) { dev::mark(2, false); dev::mark(1, true); }
-  interior_solve(d_t1_);                                    // A11 \ y1
-  if (profiling) dev::mark(1, false);
-  dev::axpby(n1_, -1.0, d_t1_, 1.0, z1);                    // x1 -= ...
-  dev::scatter(n1_, d_inperm_, z1, x);
+  if (io_fused) {
+    if (profiling) { dev::mark(2, false); dev::mark(1, true); }
+    dev::FusedIO io; io.in = 2; io.a_row = d_a12_row_; io.a_col = d_a12_col_; io.a_val = d_a12_val_; io.x2 = d_t2_;
+    io.out = 1; io.z = z1; io.user = x; io.perm = d_inperm_;
+    dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, d_t1_, &io);   // x[..] = x1 - A11 \ (A12 x2)
+    if (profiling) dev::mark(1, false);
+  } else {
+    dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0);  // y1 = A12 x2
+    if (profiling) { dev::mark(2, false); dev::mark(1, true); }
+    interior_solve(d_t1_);                                  // A11 \ y1
+    if (profiling) dev::mark(1, false);
+    dev::axpby(n1_, -1.0, d_t1_, 1.0, z1);                  // x1 -= ...
+    dev::scatter(n1_, d_inperm_, z1, x);
+  }
   dev::scatter(n2_, d_inperm_ + n1_, d_t2_, x);
   if (profiling) dev::mark(0, false);
 }

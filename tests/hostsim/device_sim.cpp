@@ -279,12 +279,20 @@ void repack_fronts(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc) {
     }
 }
 
-void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t, double* x) {
+void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t, double* x, const FusedIO* iop) {
   // level-synchronous walk with the same work-item tables the HIP kernel uses
-  std::vector<double> C, Fv, out;
+  const FusedIO io = iop ? *iop : FusedIO();
+  std::vector<double> C, Fv, out, Xl;
   for (int b = 0; b < nsub; b++) {
     const PlanD& P = plans[subs[b].cls];
-    double* X = x + subs[b].xoff;
+    const int xoff = subs[b].xoff;
+    Xl.assign(std::max(P.nI, 1), 0.0);
+    for (int i = 0; i < P.nI; i++) {
+      if (io.in == 0) Xl[i] = x[xoff + i];
+      else if (io.in == 1) Xl[i] = io.b[io.perm[xoff + i]];
+      else { double v = 0; for (int e = io.a_row[xoff + i]; e < io.a_row[xoff + i + 1]; e++) v += io.a_val[e] * io.x2[io.a_col[e]]; Xl[i] = v; }
+    }
+    double* X = Xl.data();
     const double* fac = subs[b].fac;
     C.assign(std::max(P.contrib_size, 1), 0.0);
     Fv.assign(std::max(P.max_level_rows, 1), 0.0);
@@ -325,6 +333,10 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
         const FrontD& F = P.fronts[P.bw_items[it] >> 16];
         X[F.c0 + (P.bw_items[it] & 0xffff)] = out[it - P.bw_ptr[lev]];
       }
+    }
+    for (int i = 0; i < P.nI; i++) {
+      if (io.out == 0) x[xoff + i] = X[i];
+      else io.user[io.perm[xoff + i]] = io.z[xoff + i] - X[i];
     }
   }
 }

@@ -204,3 +204,14 @@ def test_reference_driven_cavity_2d(hostsim_lib, re, part, levels, its_max):
     """2D Navier-Stokes Jacobians of the reference's test data (nonsymmetric at Re 1000), solved to the
     reference's stored solution; same GMRES iteration count as the oracle."""
     cavity2d_case(hostsim_lib, re, part, levels, its_max)
+
+
+def test_io_fusion_option(hostsim_lib, monkeypatch):
+    """HYMLS_MI_IO_FUSION=1: entry gather, A12 x2, the x1 update and the exit scatter fused into the interior solves"""
+    A, tv = problem("Stokes-C", 16)
+    prm = xml_params("Stokes-C", 16, 8, 1, partitioner="Skew Cartesian")
+    b = np.random.default_rng(13).uniform(-1, 1, A.shape[0])
+    x_plain = product_prec(A, tv, prm, hostsim_lib).ApplyInverse(b)
+    monkeypatch.setenv("HYMLS_MI_IO_FUSION", "1")
+    x_fused = product_prec(A, tv, prm, hostsim_lib).ApplyInverse(b)
+    assert rel_diff(x_fused, x_plain) < 1e-13

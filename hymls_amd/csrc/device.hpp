@@ -100,7 +100,7 @@ void axpby(int64_t n, double a, const double* x, double b, double* y);          
 void scale_copy(int64_t n, double a, const double* x, double* y);                // y = a x
 // y = alpha * A x + beta * y, CSR with 32-bit indices
 void spmv(int32_t nrows, const int32_t* rowptr, const int32_t* col, const double* val,
-          const double* x, double* y, double alpha, double beta);
+          const double* x, double* y, double alpha, double beta, int64_t nnz_hint = -1);
 // out[e] = sum_{t in [ptr[e],ptr[e+1])} in[idx[t]]   (deterministic pull-assembly)
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out);
 // out[B*blen + k] = sum_{t in [ptr[B],ptr[B+1])} in[base[t] + k], k < blen  (whole dense blocks)

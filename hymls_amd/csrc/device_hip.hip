@@ -176,15 +176,21 @@ __global__ void k_spmv(int32_t nrows, const int32_t* __restrict__ rp, const int3
   if (row < nrows && lane == 0) y[row] = alpha * s + (beta == 0.0 ? 0.0 : beta * y[row]);
 }
 void spmv(int32_t nrows, const int32_t* rp, const int32_t* col, const double* val, const double* x, double* y,
-          double alpha, double beta) {
+          double alpha, double beta, int64_t nnz_hint) {
   if (nrows <= 0) return;
-  // lanes per row from the average row length is decided by the caller-independent heuristic
-  // below: the CSR arrays live on the device, so use a fixed 4 lanes (rows here have 1-33 nnz).
-  const int L = 4;
+  // lanes per row from the average row length (the CSR arrays live on the device: the caller passes nnz if it
+  // knows it; 4 lanes otherwise, rows here have 1-33 nnz)
+  const double avg = nnz_hint >= 0 ? (double)nnz_hint / nrows : 8.0;
+  const int L = avg < 2.5 ? 1 : (avg < 5.0 ? 2 : (avg < 20.0 ? 4 : 8));
   const int64_t nt = (int64_t)nrows * L;
-  hipLaunchKernelGGL(k_spmv<4>, dim3(nblocks(nt, 256)), dim3(256), 0, g_stream, nrows, rp, col, val, x, y, alpha, beta);
+  const dim3 grid(nblocks(nt, 256));
+  switch (L) {
+    case 1: hipLaunchKernelGGL(k_spmv<1>, grid, dim3(256), 0, g_stream, nrows, rp, col, val, x, y, alpha, beta); break;
+    case 2: hipLaunchKernelGGL(k_spmv<2>, grid, dim3(256), 0, g_stream, nrows, rp, col, val, x, y, alpha, beta); break;
+    case 4: hipLaunchKernelGGL(k_spmv<4>, grid, dim3(256), 0, g_stream, nrows, rp, col, val, x, y, alpha, beta); break;
+    default: hipLaunchKernelGGL(k_spmv<8>, grid, dim3(256), 0, g_stream, nrows, rp, col, val, x, y, alpha, beta); break;
+  }
   launch_check();
-  (void)L;
 }
 
 __global__ void k_pull_sum(int64_t n, const int64_t* __restrict__ ptr, const int64_t* __restrict__ idx,

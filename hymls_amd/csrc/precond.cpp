@@ -1546,7 +1546,7 @@ void LevelSolver::apply_inverse(const double* b, double* x) {
   }
   if (profiling) { dev::mark(1, false); dev::mark(2, true); }
   xch_int_.forward(z1, z1);                                 // halo: interior layer of the neighbouring ranks
-  dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1, z2, -1.0, 1.0);  // b2 - A21 x1
+  dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1, z2, -1.0, 1.0, (int64_t)a21_col_.size());  // b2 - A21 x1
   if (profiling) { dev::mark(2, false); dev::mark(3, true); }
   schur_apply(z2, d_t2_);                                   // x2
   if (profiling) { dev::mark(3, false); dev::mark(2, true); }
@@ -1558,7 +1558,7 @@ void LevelSolver::apply_inverse(const double* b, double* x) {
     dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, d_t1_, &io);   // x[..] = x1 - A11 \ (A12 x2)
     if (profiling) dev::mark(1, false);
   } else {
-    dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0);  // y1 = A12 x2
+    dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0, (int64_t)a12_col_.size());  // y1 = A12 x2
     if (profiling) { dev::mark(2, false); dev::mark(1, true); }
     interior_solve(d_t1_);                                  // A11 \ y1
     if (profiling) dev::mark(1, false);

@@ -47,7 +47,7 @@ void scatter(int64_t n, const int32_t* idx, const double* src, double* dst) { fo
 void axpby(int64_t n, double a, const double* x, double b, double* y) { for (int64_t i = 0; i < n; i++) y[i] = a * x[i] + b * y[i]; }
 void scale_copy(int64_t n, double a, const double* x, double* y) { for (int64_t i = 0; i < n; i++) y[i] = a * x[i]; }
 void spmv(int32_t nrows, const int32_t* rp, const int32_t* col, const double* val, const double* x, double* y,
-          double alpha, double beta) {
+          double alpha, double beta, int64_t) {
   for (int i = 0; i < nrows; i++) {
     double s = 0;
     for (int e = rp[i]; e < rp[i + 1]; e++) s += val[e] * x[col[e]];

@@ -213,7 +213,7 @@ double dot(int64_t n, const double* x, const double* y);
 void solve_transposed(const PlanD& P, const BatchD& B, const int32_t* order, int32_t nfronts, int32_t max_rows, double* x);
 
 // all separator blocks of a level in one launch (blocks of any order; heavy ones first)
-struct BlkD { const double* binv; const int32_t* ids; int32_t nb, pad; };
+struct BlkD { const double* binv; const int32_t* ids; int32_t nb, r0; };   // r0 < 0: all rows; else rows [r0, r0 + 64) (tiles of a large block)
 void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, double* y);
 // in-place inverse (partial pivoting) of every block of the table, one launch
 void dense_invert_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, int32_t* flag);

@@ -1768,7 +1768,8 @@ __global__ void __launch_bounds__(64) k_blocks_apply_all(const BlkD* __restrict_
   const int nb = D.nb;
   for (int j = threadIdx.x; j < nb; j += 64) xs[j] = x[D.ids[j]];
   __syncthreads();
-  for (int i = threadIdx.x; i < nb; i += 64) {
+  const int i0 = D.r0 < 0 ? 0 : D.r0, i1 = D.r0 < 0 ? nb : min(nb, D.r0 + 64);
+  for (int i = i0 + threadIdx.x; i < i1; i += 64) {
     const double* __restrict__ M = D.binv + i;
     double a[8];
 #pragma unroll

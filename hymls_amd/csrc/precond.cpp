@@ -461,7 +461,7 @@ LevelSolver::~LevelSolver() {
                   d_nrhs_, d_nsol_};
   for (void* q : ptrs) dev::free(q);
   dev::free(d_fsubs_); dev::free(d_fplans_);
-  dev::free(d_blkd_);
+  dev::free(d_blkd_); dev::free(d_blka_);
   { void* bp[] = {d_bVu_, d_bWu_, d_bW1_, d_bQ1_, d_bSV_, d_bSW_, d_bNV_, d_bNW_, d_btmp_, d_a12t_row_, d_a12t_col_, d_a12t_src_, d_a12t_val_};
     for (void* q : bp) dev::free(q);
     for (int32_t* q : d_orders_) dev::free(q); }
@@ -1123,17 +1123,27 @@ void LevelSolver::build_schur_setup() {
       B.d_binv = (double*)dev::alloc((size_t)B.nb * B.nb * B.nblk * sizeof(double));
     }
     {
-      // one descriptor per block, largest first, for the single-launch apply
-      std::vector<dev::BlkD> bd;
+      // one descriptor per block, largest first, for the single-launch inversion; for the apply the large blocks
+      // (coarser levels: orders of 1000+) are cut into 64-row tiles so that many waves share one block
+      std::vector<dev::BlkD> bd, ba;
       blk_max_nb_ = 0;
+      const int tile_min = std::getenv("HYMLS_MI_BLOCK_TILE_MIN") ? std::atoi(std::getenv("HYMLS_MI_BLOCK_TILE_MIN")) : 128;
       for (auto& B : blocks_) {
-        for (int q = 0; q < B.nblk; q++)
-          bd.push_back(dev::BlkD{B.d_binv + (int64_t)q * B.nb * B.nb, B.d_ids + (int64_t)q * B.nb, B.nb, 0});
+        for (int q = 0; q < B.nblk; q++) {
+          const dev::BlkD D{B.d_binv + (int64_t)q * B.nb * B.nb, B.d_ids + (int64_t)q * B.nb, B.nb, -1};
+          bd.push_back(D);
+          if (B.nb <= tile_min) ba.push_back(D);
+          else for (int r0 = 0; r0 < B.nb; r0 += 64) { dev::BlkD T = D; T.r0 = r0; ba.push_back(T); }
+        }
         blk_max_nb_ = std::max(blk_max_nb_, B.nb);
       }
-      std::stable_sort(bd.begin(), bd.end(), [](const dev::BlkD& a, const dev::BlkD& b) { return a.nb > b.nb; });
+      auto by_size = [](const dev::BlkD& a, const dev::BlkD& b) { return a.nb > b.nb; };
+      std::stable_sort(bd.begin(), bd.end(), by_size);
+      std::stable_sort(ba.begin(), ba.end(), by_size);
       n_blk_ = (int32_t)bd.size();
       d_blkd_ = dev::upload(bd);
+      n_blk_apply_ = (int32_t)ba.size();
+      d_blka_ = dev::upload(ba);
     }
     d_gptr_ = dev::upload(gptr_); d_otw_ = dev::upload(otw_); d_vs_ = dev::upload(vs_);
     d_vrhs_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
@@ -1515,7 +1525,7 @@ void LevelSolver::schur_apply(double* rhs2, double* x2) {
   // SchurPreconditioner::ApplyInverse (reference src/HYMLS_SchurPreconditioner.cpp:1010-1093)
   const int ng = (int)vs_.size();
   dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);                       // B' = H rhs
-  dev::blocks_apply_all(n_blk_, d_blkd_, blk_max_nb_, rhs2, x2);
+  dev::blocks_apply_all(n_blk_apply_, d_blka_, blk_max_nb_, rhs2, x2);
   dev::gather(ng, d_vs_, rhs2, d_vrhs_);
   if (profiling && level_ == 0) dev::mark(4, true);
   next_apply(d_vrhs_, d_vsol_);
@@ -1731,7 +1741,7 @@ void LevelSolver::schur_apply_bordered(double* rhs2, const double* q, double* x2
   const int ng = (int)vs_.size(), m = bm_;
   dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);
   dev::zero(x2, (size_t)n2_ * sizeof(double));                          // V-sum entries are zero in W'(M11 \ f1)
-  dev::blocks_apply_all(n_blk_, d_blkd_, blk_max_nb_, rhs2, x2);
+  dev::blocks_apply_all(n_blk_apply_, d_blka_, blk_max_nb_, rhs2, x2);
   dvec tc(m);
   for (int j = 0; j < m; j++) tc[j] = q[j] - dev::dot(n2_, d_bSW_ + (size_t)j * n2_, x2);
   dev::gather(ng, d_vs_, rhs2, d_vrhs_);

@@ -240,8 +240,9 @@ class LevelSolver : public Operator {
   struct BlockClass { int32_t nb = 0, nblk = 0; ivec ids; ivec owner_key; double* d_binv = nullptr; int32_t* d_ids = nullptr;
                       std::vector<int64_t> pull_ptr, pull_base; int64_t* d_pull_ptr = nullptr; int64_t* d_pull_base = nullptr; };
   std::vector<BlockClass> blocks_;
-  dev::BlkD* d_blkd_ = nullptr;   // all blocks, for the single-launch apply
-  int32_t n_blk_ = 0, blk_max_nb_ = 0;
+  dev::BlkD* d_blkd_ = nullptr;   // all blocks (single-launch inversion)
+  dev::BlkD* d_blka_ = nullptr;   // apply tasks: small blocks whole, large blocks in 64-row tiles
+  int32_t n_blk_ = 0, n_blk_apply_ = 0, blk_max_nb_ = 0;
   // rows of the reduced (V-sum) matrix or of the full Schur complement owned here: pattern + pull lists
   Csr red_;                  // col = gid of the column node
   std::vector<int64_t> red_pull_ptr_, red_pull_idx_;

@@ -478,12 +478,13 @@ void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t, const double* x
     const BlkD& D = blocks[b];
     xs.resize(D.nb); out.resize(D.nb);
     for (int j = 0; j < D.nb; j++) xs[j] = x[D.ids[j]];
-    for (int i = 0; i < D.nb; i++) {
+    const int i0 = D.r0 < 0 ? 0 : D.r0, i1 = D.r0 < 0 ? D.nb : std::min(D.nb, D.r0 + 64);
+    for (int i = i0; i < i1; i++) {
       double s = 0;
       for (int j = 0; j < D.nb; j++) s += D.binv[i + (int64_t)D.nb * j] * xs[j];
       out[i] = s;
     }
-    for (int i = 0; i < D.nb; i++) y[D.ids[i]] = out[i];
+    for (int i = i0; i < i1; i++) y[D.ids[i]] = out[i];
   }
 }
 

@@ -215,3 +215,14 @@ def test_io_fusion_option(hostsim_lib, monkeypatch):
     monkeypatch.setenv("HYMLS_MI_IO_FUSION", "1")
     x_fused = product_prec(A, tv, prm, hostsim_lib).ApplyInverse(b)
     assert rel_diff(x_fused, x_plain) < 1e-13
+
+
+def test_tiled_separator_block_apply(hostsim_lib, monkeypatch):
+    """large separator blocks are applied in 64-row tiles (one wave each); force the tiling on small blocks"""
+    A, tv = problem("Stokes-C", 16)
+    prm = xml_params("Stokes-C", 16, 8, 1, partitioner="Skew Cartesian")
+    b = np.random.default_rng(14).uniform(-1, 1, A.shape[0])
+    x_plain = product_prec(A, tv, prm, hostsim_lib).ApplyInverse(b)
+    monkeypatch.setenv("HYMLS_MI_BLOCK_TILE_MIN", "8")
+    x_tiled = product_prec(A, tv, prm, hostsim_lib).ApplyInverse(b)
+    assert rel_diff(x_tiled, x_plain) < 1e-13

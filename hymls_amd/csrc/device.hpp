@@ -24,6 +24,14 @@ size_t mem_free();
 // process-wide setup scratch (frontal matrices, separator blocks, pivot-piece workspace): factorisations run one
 // after the other on the stream, so every batch borrows the same arena; grown on demand (synchronises when it grows)
 void* shared_scratch(size_t bytes);
+// side streams for independent setup work (the many small batches of the coarser levels would otherwise run one tiny
+// launch after the other): fork_streams() makes the side streams wait for the main one, use_stream(k) directs every
+// following launch / copy / scratch request to stream k (0 = main, 1..NSIDE), join_streams() makes the main stream wait
+// for all of them and switches back to it
+constexpr int NSIDE = 4;
+void fork_streams();
+void use_stream(int k);
+void join_streams();
 // event timing on the stream (seconds); ids are small integers
 void timer_start(int id);
 double timer_stop(int id);  // synchronises

@@ -31,7 +31,11 @@ namespace dev {
                                    __FILE__ + ":" + std::to_string(__LINE__));             \
   } while (0)
 
-static hipStream_t g_stream = nullptr;
+static hipStream_t g_stream = nullptr;      // the stream every launcher uses (main or one of the side streams)
+static hipStream_t g_main = nullptr, g_side[NSIDE];
+static hipEvent_t g_fork_ev, g_join_ev[NSIDE];
+static int g_cur = 0;
+static bool g_side_init = false;
 static bool g_init = false;
 static hipEvent_t g_ev[16][2];
 static bool g_ev_init = false;
@@ -44,10 +48,30 @@ void init(int device) {
   HIP_CHECK(hipSetDevice(device));
   if (!g_init) {
     HIP_CHECK(hipStreamCreate(&g_stream));
+    g_main = g_stream;
     g_init = true;
   }
 }
-void* stream() { return (void*)g_stream; }
+void* stream() { return (void*)g_main; }
+void fork_streams() {
+  if (!g_side_init) {
+    for (int k = 0; k < NSIDE; k++) { HIP_CHECK(hipStreamCreate(&g_side[k])); HIP_CHECK(hipEventCreateWithFlags(&g_join_ev[k], hipEventDisableTiming)); }
+    HIP_CHECK(hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming));
+    g_side_init = true;
+  }
+  HIP_CHECK(hipEventRecord(g_fork_ev, g_main));
+  for (int k = 0; k < NSIDE; k++) HIP_CHECK(hipStreamWaitEvent(g_side[k], g_fork_ev, 0));
+}
+void use_stream(int k) { g_cur = k; g_stream = k == 0 ? g_main : g_side[k - 1]; }
+static void* g_arena[NSIDE + 1] = {nullptr};     // setup scratch, one arena per stream
+static size_t g_arena_cap[NSIDE + 1] = {0};
+void join_streams() {
+  for (int k = 0; k < NSIDE; k++) { HIP_CHECK(hipEventRecord(g_join_ev[k], g_side[k])); HIP_CHECK(hipStreamWaitEvent(g_main, g_join_ev[k], 0)); }
+  use_stream(0);
+  // the side arenas are only needed while the side streams run: give the memory back
+  for (int k = 1; k <= NSIDE; k++)
+    if (g_arena[k]) { HIP_CHECK(hipStreamSynchronize(g_side[k - 1])); (void)hipFree(g_arena[k]); g_arena[k] = nullptr; g_arena_cap[k] = 0; }
+}
 void* alloc(size_t bytes) {
   void* p = nullptr;
   HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 8)));
@@ -70,17 +94,15 @@ void d2d(void* d, const void* s, size_t n) {
 }
 void zero(void* d, size_t n) { if (n) HIP_CHECK(hipMemsetAsync(d, 0, n, g_stream)); }
 void sync() { HIP_CHECK(hipStreamSynchronize(g_stream)); }
-static void* g_arena = nullptr;
-static size_t g_arena_cap = 0;
 void* shared_scratch(size_t bytes) {
-  if (bytes > g_arena_cap) {
+  if (bytes > g_arena_cap[g_cur]) {
     sync();
-    if (g_arena) (void)hipFree(g_arena);
-    g_arena = nullptr; g_arena_cap = 0;
-    g_arena = alloc(bytes);
-    g_arena_cap = bytes;
+    if (g_arena[g_cur]) (void)hipFree(g_arena[g_cur]);
+    g_arena[g_cur] = nullptr; g_arena_cap[g_cur] = 0;
+    g_arena[g_cur] = alloc(bytes);
+    g_arena_cap[g_cur] = bytes;
   }
-  return g_arena;
+  return g_arena[g_cur];
 }
 size_t mem_free() { size_t f = 0, t = 0; HIP_CHECK(hipMemGetInfo(&f, &t)); return f; }
 void timer_start(int id) {

@@ -1386,10 +1386,13 @@ void LevelSolver::compute() {
   mv_stale_ = true;
   dev::gather((int64_t)a12_col_.size(), d_a12_src_, d_kval_, d_a12_val_);
   dev::gather((int64_t)a21_col_.size(), d_a21_src_, d_kval_, d_a21_val_);
-  // ---- interior factorisations + separator blocks, class by class, chunk by chunk
-  int32_t bad = 0;
-  for (auto& cp : cls_) {
-    Cls& C = *cp;
+  // ---- interior factorisations + separator blocks, class by class, chunk by chunk.  The coarser levels have many
+  // classes with one or two large subdomains each: their launch chains are independent and run on side streams
+  const bool side = level_ >= 1 && cls_.size() > 1 && !std::getenv("HYMLS_MI_NO_SIDE_STREAMS");
+  if (side) dev::fork_streams();
+  for (size_t c = 0; c < cls_.size(); c++) {
+    Cls& C = *cls_[c];
+    if (side) dev::use_stream(1 + (int)(c % dev::NSIDE));
     dev::zero(C.lu.batch.flag, sizeof(int32_t));
     const int nb = (int)C.lu.members.size();
     for (int b0 = 0; b0 < nb; b0 += C.lu.chunk) {
@@ -1402,8 +1405,10 @@ void LevelSolver::compute() {
       dev::sblock_extract(C.pat.nS, C.ext_size, C.d_pick, C.lu.batch.sblock,
                           d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size, C.ext_size, nbc);
     }
-    if (C.lu.check_flag() != 0) bad = 1;
   }
+  if (side) dev::join_streams();
+  int32_t bad = 0;
+  for (auto& cp : cls_) if (cp->lu.check_flag() != 0) bad = 1;
   // (collective: every rank has to reach the exchanges below, so errors are agreed on first)
   HYMLS_CHECK(comm_->allsum(bad) == 0, -4, "subdomain factorisation hit a zero or non-finite pivot (level " +
                                                std::to_string(level_) + ")");

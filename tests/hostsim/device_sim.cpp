@@ -21,6 +21,9 @@ void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
 void d2d(void* d, const void* s, size_t n) { std::memmove(d, s, n); }
 void zero(void* d, size_t n) { std::memset(d, 0, n); }
 void sync() {}
+void fork_streams() {}
+void use_stream(int) {}
+void join_streams() {}
 static void* g_arena = nullptr;
 static size_t g_arena_cap = 0;
 void* shared_scratch(size_t bytes) {

@@ -184,3 +184,25 @@ def test_stokes3d_integration_targets_on_the_reference_fixture(kw, max_its, tol)
     assert np.linalg.norm(e) / np.linalg.norm(sol) <= max(tol, 1e-5)
     b0 = rhs.copy(); b0[3::4] = 0.0
     assert np.abs((K @ P.apply_inverse(b0))[3::4]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("with_c", [True, False])
+def test_oracle_bordered_apply_inverse_is_exact_on_one_level(with_c):
+    """reference testSuite/unit_tests/HYMLS_Preconditioner.cpp:278-378 (BorderedApplyInverse, ..._without_C):
+    random V, W (n x 2), random or zero C; [K V; W' C] [X; S] = [B; T] is solved to 1e-10 by the one-level method."""
+    import numpy as np
+    from oracle import galeri
+    from oracle.partition import Params
+    from oracle.hymls import Preconditioner
+    A = galeri.laplace3d(8, 8, 8)
+    N, m = A.shape[0], 2
+    rng = np.random.default_rng(5)
+    V, W = rng.uniform(-1, 1, (N, m)), rng.uniform(-1, 1, (N, m))
+    C = rng.uniform(-1, 1, (m, m)) if with_c else np.zeros((m, m))
+    P = Preconditioner(A, Params(nx=8, ny=8, nz=8, sx=4, levels=0, equations="Laplace").finalize())
+    P.set_border(V, W, C if with_c else None)
+    P.compute()
+    x_ex = rng.uniform(-1, 1, N)
+    s_ex = rng.uniform(-1, 1, m) if with_c else np.zeros(m)
+    x, s = P.apply_inverse_bordered(A @ x_ex + V @ s_ex, W.T @ x_ex + C @ s_ex)
+    assert np.abs(x - x_ex).max() < 1e-10 and np.abs(s - s_ex).max() < 1e-10

@@ -67,10 +67,7 @@ static void* g_arena[NSIDE + 1] = {nullptr};     // setup scratch, one arena per
 static size_t g_arena_cap[NSIDE + 1] = {0};
 void join_streams() {
   for (int k = 0; k < NSIDE; k++) { HIP_CHECK(hipEventRecord(g_join_ev[k], g_side[k])); HIP_CHECK(hipStreamWaitEvent(g_main, g_join_ev[k], 0)); }
-  use_stream(0);
-  // the side arenas are only needed while the side streams run: give the memory back
-  for (int k = 1; k <= NSIDE; k++)
-    if (g_arena[k]) { HIP_CHECK(hipStreamSynchronize(g_side[k - 1])); (void)hipFree(g_arena[k]); g_arena[k] = nullptr; g_arena_cap[k] = 0; }
+  use_stream(0);   // (the side arenas stay allocated: re-allocating them costs about a second per Compute at 256^3)
 }
 void* alloc(size_t bytes) {
   void* p = nullptr;
@@ -1669,11 +1666,43 @@ __global__ void __launch_bounds__(256) k_sblock_hh(int32_t nS, int32_t ng, const
     for (int i = 1; i < n; i++) p[inc * i] = (sg * v[pos + i]) * fac - p[inc * i];
   }
 }
+// pass 0 with the lanes along the rows of a group: task = (group, column), eight lanes per task (groups have about 8
+// nodes), consecutive tasks = consecutive columns; every column segment is read and written once, 64 contiguous bytes
+// at a time (the thread-per-column version walked down the columns: one cache line per lane and load)
+__global__ void __launch_bounds__(256) k_sblock_hh_rows(int32_t nS, int32_t ng, const int32_t* __restrict__ gptr,
+                                                         const double* __restrict__ tv, double* __restrict__ sblock) {
+  const int slot = blockIdx.y;
+  double* S = sblock + (int64_t)slot * nS * nS;
+  const double* v = tv + (int64_t)slot * nS;
+  const int64_t t = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int lane = threadIdx.x & 7;
+  const bool on = t < (int64_t)ng * nS;
+  const int g = on ? (int)(t / nS) : 0, c = on ? (int)(t % nS) : 0;
+  const int pos = gptr[g], n = on ? gptr[g + 1] - pos : 0;
+  // Householder data of the group (hh_setup), reduced over the eight lanes
+  const double v0 = n > 0 ? v[pos] : 0.0;
+  const double sg = v0 < 0 ? -1.0 : (v0 > 0 ? 1.0 : 0.0);
+  double ss = 0.0;
+  for (int i = lane; i < n; i += 8) ss += v[pos + i] * v[pos + i];
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  const double nrm = sqrt(ss) * fabs(sg);
+  const double v1 = sg * v0 + nrm;
+  const bool act = n > 0 && !(fabs(v1) < 1e-14 || nrm < 1e-14);
+  double* p = S + (int64_t)nS * c + pos;
+  double f2 = 0.0;
+  if (act) for (int i = lane; i < n; i += 8) f2 += p[i] * (i == 0 ? nrm + sg * v0 : sg * v[pos + i]);
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) f2 += __shfl_xor(f2, off, 64);
+  if (!act) return;
+  const double fac = f2 / (nrm * v1);
+  for (int i = lane; i < n; i += 8) p[i] = (i == 0 ? v1 : sg * v[pos + i]) * fac - p[i];
+}
 void sblock_transform(int32_t nS, int32_t ng, const int32_t* gptr, const double* tv, double* sblock, int32_t nbc) {
   if (nS <= 0 || nbc <= 0) return;
   for (int s0 = 0; s0 < nbc; s0 += 65535) {
     const int ns = std::min(65535, nbc - s0);
-    hipLaunchKernelGGL(k_sblock_hh<0>, dim3((nS + 255) / 256, ns), dim3(256), 0, g_stream, nS, ng, gptr,
+    hipLaunchKernelGGL(k_sblock_hh_rows, dim3((unsigned)(((int64_t)ng * nS + 31) / 32), ns), dim3(256), 0, g_stream, nS, ng, gptr,
                        tv + (int64_t)s0 * nS, sblock + (int64_t)s0 * nS * nS);
     launch_check();
     hipLaunchKernelGGL(k_sblock_hh<1>, dim3((nS + 255) / 256, ns), dim3(256), 0, g_stream, nS, ng, gptr,

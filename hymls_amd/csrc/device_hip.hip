@@ -1731,10 +1731,11 @@ void sblock_extract(int32_t nS, int64_t npick, const int32_t* pick, const double
 // in-place Gauss-Jordan inversion with partial pivoting, one workgroup per block
 // one workgroup per block; `all` != nullptr: blocks of any order from a descriptor table (one launch for a
 // whole level, so that the few large blocks of the coarser levels run side by side), else nblk blocks of order nb0
-__global__ void __launch_bounds__(256) k_dense_invert(int32_t nb0, double* __restrict__ blocks, const BlkD* __restrict__ all, int32_t* flag) {
+template <int BS>
+__global__ void __launch_bounds__(BS) k_dense_invert(int32_t nb0, double* __restrict__ blocks, const BlkD* __restrict__ all, int32_t* flag) {
   extern __shared__ int piv[];   // nb ints, then reduction scratch
-  __shared__ double red_v[256];
-  __shared__ int red_i[256];
+  __shared__ double red_v[BS];
+  __shared__ int red_i[BS];
   const int nb = all ? all[blockIdx.x].nb : nb0;
   double* A = all ? const_cast<double*>(all[blockIdx.x].binv) : blocks + (int64_t)blockIdx.x * nb * nb;
   const int tid = threadIdx.x;
@@ -1788,12 +1789,16 @@ __global__ void __launch_bounds__(256) k_dense_invert(int32_t nb0, double* __res
 void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag) {
   if (nb <= 0 || nblk <= 0) return;
   const int bs = nb <= 64 ? 64 : 256;
-  hipLaunchKernelGGL(k_dense_invert, dim3(nblk), dim3(bs), (size_t)nb * sizeof(int), g_stream, nb, blocks, (const BlkD*)nullptr, flag);
+  hipLaunchKernelGGL(k_dense_invert<256>, dim3(nblk), dim3(bs), (size_t)nb * sizeof(int), g_stream, nb, blocks, (const BlkD*)nullptr, flag);
   launch_check();
 }
 void dense_invert_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, int32_t* flag) {
   if (nblk <= 0) return;
-  hipLaunchKernelGGL(k_dense_invert, dim3(nblk), dim3(256), (size_t)max_nb * sizeof(int), g_stream, 0, (double*)nullptr, blocks, flag);
+  // a few large blocks (coarser levels): 1024 threads per block, the rank-1 updates are what takes the time
+  if (max_nb > 256 && nblk <= 4096)
+    hipLaunchKernelGGL(k_dense_invert<1024>, dim3(nblk), dim3(1024), (size_t)max_nb * sizeof(int), g_stream, 0, (double*)nullptr, blocks, flag);
+  else
+    hipLaunchKernelGGL(k_dense_invert<256>, dim3(nblk), dim3(256), (size_t)max_nb * sizeof(int), g_stream, 0, (double*)nullptr, blocks, flag);
   launch_check();
 }
 

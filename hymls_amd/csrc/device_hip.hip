@@ -1,22 +1,28 @@
 // device_hip.hip -- HIP (gfx950 / MI355X) implementation of the device boundary (device.hpp).
 //
 // Every floating-point operation of Compute() and ApplyInverse() runs in the kernels of this
-// file, on one stream.  Kernel overview (FP64 throughout):
+// file, on one stream (plus side streams for independent setup work).  Kernel overview (FP64 throughout):
 //   apply path (HBM-bound):
-//     k_solve_fwd / k_solve_bwd  one workgroup per (subdomain, front): the front's panel
-//                                (column-major, rows on consecutive lanes => fully coalesced
-//                                streaming reads) times an LDS-resident vector
-//     k_spmv                     CSR SpMV, L lanes per row + sub-wave shuffle reduction
-//     k_ot                       per-group Householder: wave-level dot + axpy
-//     k_blocks_apply             dense block inverse times vector (GEMV per block)
-//     k_gather/k_scatter/k_axpby vector glue
+//     k_interior_fused           one workgroup per subdomain walks its whole assembly tree level by level with
+//                                the solution, the contribution vectors and the front descriptors in LDS; the
+//                                factor panels (column-major or packed, rows on consecutive lanes) are streamed once
+//     k_lvl_fwd / k_lvl_bwd      subdomains too large for LDS: one launch per tree level for all classes, a task is a
+//                                whole small front or a 64-row tile of a large one
+//     k_solve_* / k_panel_*      the coarse direct solver (one class, one member): small fronts per workgroup,
+//                                wide supernodes as tiled panel-times-vector products with a fixed-order finalize
+//     k_spmv                     CSR SpMV, 1-8 lanes per row + sub-wave shuffle reduction
+//     k_ot                       per-group Householder: 8 lanes per group, dot + axpy
+//     k_blocks_apply_all         dense block inverse times vector for every separator block of a level
+//     k_gather/k_scatter/k_axpby vector glue and exchange packing
 //   setup path:
-//     k_factor_level             multifrontal front: assemble, LU of the pivot block,
-//                                triangular inverses, panel products and the Schur update as
-//                                workgroup-level tiled GEMMs (LDS staged)
+//     k_factor_level             multifrontal front: assemble, LU of the pivot block, triangular inverses, panel
+//                                products and the Schur update as workgroup-level tiled GEMMs (LDS staged)
+//     k_big_* / k_gemm_f64       wide supernodes spread over many workgroups; FP64 MFMA GEMMs with triangular masks
+//     k_repack                   packed L-side panels for the classes of the fused solve
 //     k_sblock_*                 separator block init / two-sided Householder / extraction
 //     k_dense_invert             in-place Gauss-Jordan with partial pivoting per block
 //     k_pull_sum*                deterministic assembly of the kept Schur entries
+//     k_solve_transposed, k_dot  bordered systems
 #include <hip/hip_runtime.h>
 #include "device.hpp"
 

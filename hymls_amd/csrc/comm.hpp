@@ -52,11 +52,19 @@ struct Comm {
   template <class T>
   std::vector<T> allgather(const std::vector<T>& mine, std::vector<int64_t>* counts = nullptr) const {
     if (!distributed()) { if (counts) counts->assign(1, (int64_t)mine.size()); return mine; }
-    std::vector<std::vector<T>> out(size, mine);
-    auto in = exchange_lists(out);
-    std::vector<T> all;
-    if (counts) counts->clear();
-    for (int q = 0; q < size; q++) { all.insert(all.end(), in[q].begin(), in[q].end()); if (counts) counts->push_back((int64_t)in[q].size()); }
+    // all-to-all with the same segment for every peer: the receive buffer IS the concatenation in rank order
+    std::vector<int64_t> sc(size, (int64_t)mine.size());
+    std::vector<int64_t> rc = exchange_counts(sc);
+    int64_t nr = 0;
+    for (int64_t c : rc) nr += c;
+    std::vector<T> sbuf;
+    sbuf.reserve(std::max<size_t>(1, mine.size() * (size_t)size));
+    for (int q = 0; q < size; q++) sbuf.insert(sbuf.end(), mine.begin(), mine.end());
+    if (sbuf.empty()) sbuf.resize(1);
+    std::vector<T> all((size_t)std::max<int64_t>(nr, 1));
+    a2a_host(sbuf.data(), sc, all.data(), rc, (int)sizeof(T));
+    all.resize((size_t)nr);
+    if (counts) *counts = rc;
     return all;
   }
   int64_t allsum(int64_t v) const;

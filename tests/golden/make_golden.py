@@ -9,7 +9,8 @@ Run once in the dev container (needs /root/reference):  python tests/golden/make
   reference's integration tests stokes{0,1,2}_3D.xml), stored as float64 arrays.
 * stokes3d_4.npz : the restated generator's 4^3 matrix (a=1/4, b=1/16) after it reproduced the
   fixture bit for bit, as a small known-answer vector for the C++ generator.
-* drivencavity32_2d_re{0,1000}.npz : jac.mtx / rhs.mtx / sol.mtx of testSuite/data/DrivenCavity/32x32/Re{0,1000}
+* drivencavity32_2d_re{0,1000}.npz, drivencavity64_2d_re1000.npz : jac.mtx / rhs.mtx / sol.mtx of
+  testSuite/data/DrivenCavity/{32x32/Re0, 32x32/Re1000, 64x64/Re1000}
   (the input of testSuite/cavity.xml): a 2D Navier-Stokes Jacobian (3 dof per cell, nonsymmetric at Re 1000)
   with its right-hand side and solution, as CSR arrays.
 """
@@ -54,11 +55,11 @@ def main():
     np.savez_compressed(os.path.join(HERE, "drivencavity16_rhs_sol.npz"), rhs=rhs, sol=sol)
     A4 = galeri.stokes3d(4, 4, 4, a=0.25, b=1.0 / 16)
     np.savez_compressed(os.path.join(HERE, "stokes3d_4.npz"), indptr=A4.indptr, indices=A4.indices, data=A4.data)
-    for re in ("Re0", "Re1000"):
-        d2 = "/root/reference/testSuite/data/DrivenCavity/32x32/%s/" % re
+    for grid, re in ((32, "Re0"), (32, "Re1000"), (64, "Re1000")):
+        d2 = "/root/reference/testSuite/data/DrivenCavity/%dx%d/%s/" % (grid, grid, re)
         J = scipy.io.mmread(d2 + "jac.mtx").tocsr()
         J.sum_duplicates(); J.sort_indices()
-        np.savez_compressed(os.path.join(HERE, "drivencavity32_2d_%s.npz" % re.lower()),
+        np.savez_compressed(os.path.join(HERE, "drivencavity%d_2d_%s.npz" % (grid, re.lower())),
                             indptr=J.indptr.astype(np.int32), indices=J.indices.astype(np.int32), data=J.data,
                             rhs=np.asarray(scipy.io.mmread(d2 + "rhs.mtx")).ravel(),
                             sol=np.asarray(scipy.io.mmread(d2 + "sol.mtx")).ravel())

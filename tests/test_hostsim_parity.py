@@ -164,25 +164,26 @@ def test_darcy3d_saddle_point(hostsim_lib, levels):
     assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-8
 
 
-def _cavity2d(re):
+def _cavity2d(re, grid=32):
     """the reference's own 2D driven-cavity linear system (testSuite/data/DrivenCavity/32x32/<re>, input of
     testSuite/cavity.xml), committed as a fixture by tests/golden/make_golden.py"""
     import os
     import scipy.sparse as sp
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "drivencavity32_2d_%s.npz" % re))
-    A = sp.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=(3072, 3072))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "drivencavity%d_2d_%s.npz" % (grid, re)))
+    n = 3 * grid * grid
+    A = sp.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=(n, n))
     return A, z["rhs"], z["sol"]
 
 
-def cavity2d_case(lib, re, part, levels, its_max):
+def cavity2d_case(lib, re, part, levels, its_max, grid=32):
     from oracle import galeri, krylov
-    A, rhs, sol = _cavity2d(re)
+    A, rhs, sol = _cavity2d(re, grid)
     assert np.linalg.norm(A @ sol - rhs) <= 1e-12 * np.linalg.norm(rhs)          # the fixture is consistent
     tv = galeri.create_testvector(A)
-    prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 2, "nx": 32, "ny": 32, "nz": 1},
+    prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 2, "nx": grid, "ny": grid, "nz": 1},
            "Preconditioner": {"Separator Length": 4, "Number of Levels": levels, "Partitioner": part}}
     P = product_prec(A, tv, prm, lib)
-    O = OraclePrec2D(A, tv, part, levels)
+    O = OraclePrec2D(A, tv, part, levels, grid)
     b = np.random.default_rng(31).uniform(-1, 1, A.shape[0])
     assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-9
     x, its, res = krylov.gmres(lambda v: A @ v, rhs, P.ApplyInverse, tol=1e-8, maxit=250)
@@ -192,9 +193,9 @@ def cavity2d_case(lib, re, part, levels, its_max):
     assert np.linalg.norm((x - sol)[vel]) <= 1e-6 * np.linalg.norm(sol[vel])
 
 
-def OraclePrec2D(A, tv, part, levels):
+def OraclePrec2D(A, tv, part, levels, grid=32):
     from oracle.hymls import Preconditioner as OraclePrec
-    p = Params(nx=32, ny=32, nz=1, sx=4, levels=levels, equations="Stokes-C", dim=2, partitioner=part).finalize()
+    p = Params(nx=grid, ny=grid, nz=1, sx=4, levels=levels, equations="Stokes-C", dim=2, partitioner=part).finalize()
     return OraclePrec(A, p, testvector=tv).compute()
 
 
@@ -204,6 +205,11 @@ def test_reference_driven_cavity_2d(hostsim_lib, re, part, levels, its_max):
     """2D Navier-Stokes Jacobians of the reference's test data (nonsymmetric at Re 1000), solved to the
     reference's stored solution; same GMRES iteration count as the oracle."""
     cavity2d_case(hostsim_lib, re, part, levels, its_max)
+
+
+def test_reference_driven_cavity_2d_64(hostsim_lib):
+    """the 64x64 Re 1000 system SURVEY 8d names as the reference-pinned robustness check (3-level)"""
+    cavity2d_case(hostsim_lib, "re1000", "Cartesian", 2, 250, grid=64)
 
 
 def test_io_fusion_option(hostsim_lib, monkeypatch):

@@ -85,6 +85,8 @@ class TorchComm:
         if host_group is None and backend != "gloo":
             host_group = dist.new_group(backend="gloo")   # collective: every rank constructs its TorchComm
         self.host_group = host_group if backend != "gloo" else (host_group or device_group)
+        import os
+        self.host_chunk = int(os.environ.get("HYMLS_MI_HOST_CHUNK_BYTES", str(256 << 20)))   # bytes per peer and round
         self._arenas = []          # (ptr, nbytes, tensor)
         self._stream = None
         self._a2a = A2A_FN(self._alltoallv)
@@ -135,11 +137,31 @@ class TorchComm:
                 else:
                     dist.all_to_all_single(out, inp, rc, sc, group=self.device_group)
             else:
-                nb_s, nb_r = sum(sc) * elem_bytes, sum(rc) * elem_bytes
+                sb, rb = [c * elem_bytes for c in sc], [c * elem_bytes for c in rc]
+                nb_s, nb_r = sum(sb), sum(rb)
                 inp = torch.frombuffer((C.c_char * max(nb_s, 1)).from_address(send), dtype=torch.uint8)[:nb_s]
                 out = torch.frombuffer((C.c_char * max(nb_r, 1)).from_address(recv), dtype=torch.uint8)[:nb_r]
-                dist.all_to_all_single(out, inp, [c * elem_bytes for c in rc], [c * elem_bytes for c in sc],
-                                       group=self.host_group)
+                # large setup exchanges (the reduced matrix of a 256^3 run is GBs) go in rounds of bounded size; the
+                # number of rounds has to be the same on every rank
+                big = torch.tensor([max(sb + rb + [0])], dtype=torch.int64)
+                dist.all_reduce(big, op=dist.ReduceOp.MAX, group=self.host_group)
+                rounds = max(1, -(-int(big.item()) // self.host_chunk))
+                if rounds == 1:
+                    dist.all_to_all_single(out, inp, rb, sb, group=self.host_group)
+                else:
+                    so = np.concatenate([[0], np.cumsum(sb)]).astype(np.int64)
+                    ro = np.concatenate([[0], np.cumsum(rb)]).astype(np.int64)
+                    ch = self.host_chunk
+                    for r in range(rounds):
+                        ss = [min(max(b - r * ch, 0), ch) for b in sb]
+                        rs = [min(max(b - r * ch, 0), ch) for b in rb]
+                        ti = torch.cat([inp[so[q] + r * ch: so[q] + r * ch + ss[q]] for q in range(self.size)])
+                        to = torch.empty(sum(rs), dtype=torch.uint8)
+                        dist.all_to_all_single(to, ti, rs, ss, group=self.host_group)
+                        o = 0
+                        for q in range(self.size):
+                            out[ro[q] + r * ch: ro[q] + r * ch + rs[q]] = to[o:o + rs[q]]
+                            o += rs[q]
             return 0
         except Exception as e:
             self.error = e

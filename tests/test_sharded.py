@@ -58,3 +58,10 @@ def test_sharded_geometric_halo_prefilter(hostsim_lib, world, eq, nx, ny, nz, sx
                      env_extra={"HYMLS_MI_HALO_ALL_BELOW": "0"})
     assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
     assert res["rel_err"] < 1e-12
+
+
+def test_sharded_host_exchange_in_rounds(hostsim_lib):
+    """setup exchanges larger than the per-round limit are cut into rounds (here: 1 kB rounds)"""
+    res = run_worker(4, ("Laplace", 16, 16, 8, 4, 1, -1, "Cartesian"), "hostsim", 29575,
+                     env_extra={"HYMLS_MI_HOST_CHUNK_BYTES": "1024"})
+    assert res["cover_ok"] and res["rel_err"] < 1e-12 and res["matvec_err"] < 1e-13

@@ -833,18 +833,20 @@ void LevelSolver::build_classes() {
     const int64_t c1 = std::min<int64_t>(c0 + CHUNK, (int64_t)my_sds_.size());
     std::vector<SdPat> pats((size_t)(c1 - c0));
     parallel_for(c1 - c0, [&](int64_t k) { build_pattern(my_sds_[c0 + k], pats[k]); }, 1);
+    ivec assigned((size_t)(c1 - c0), -1);
+    std::vector<char> is_new((size_t)(c1 - c0), 0);
     for (int64_t k = 0; k < c1 - c0; k++) {
       SdPat& Pt = pats[k];
       HYMLS_CHECK(Pt.err.empty(), Pt.err.find("decouple") != std::string::npos ? -2 : -3, Pt.err);
       const int s = my_sds_[c0 + k];
       const Subdomain& S = hm_.sd[s];
       LocalPattern& lp = Pt.lp;
+      // the class is found through the 64-bit hash of everything that defines it (and a size check); the full
+      // comparison with the class representative runs in parallel below
       int cid = -1;
       for (int c : table[Pt.hash]) {
         Cls& C = *cls_[c];
-        if (C.pat.nI == lp.nI && C.pat.nS == lp.nS && C.pat.rowptr == lp.rowptr && C.pat.col == lp.col &&
-            C.pat.zero_diag == lp.zero_diag && C.pat.coord == lp.coord && C.mult == Pt.mult && C.lgptr == Pt.lgptr &&
-            C.key_extra == Pt.key_extra) { cid = c; break; }
+        if (C.pat.nI == lp.nI && C.pat.nS == lp.nS && C.pat.col.size() == lp.col.size() && C.lgptr.size() == Pt.lgptr.size()) { cid = c; break; }
       }
       if (cid < 0) {
         cid = (int)cls_.size();
@@ -855,7 +857,9 @@ void LevelSolver::build_classes() {
         C.llinked = S.linked;
         C.ngl = (int32_t)S.groups.size();
         table[Pt.hash].push_back(cid);
+        is_new[k] = 1;
       }
+      assigned[k] = cid;
       Cls& C = *cls_[cid];
       sd_cls_[s] = cid;
       sd_bidx_[s] = (int32_t)C.lu.members.size();
@@ -863,6 +867,16 @@ void LevelSolver::build_classes() {
       // map the class's entry numbering (plan.ent_id refers to the extended CSR) onto this member
       C.lu.h_src.insert(C.lu.h_src.end(), Pt.src.begin(), Pt.src.end());
     }
+    std::atomic<int> mismatch{0};
+    parallel_for(c1 - c0, [&](int64_t k) {
+      if (is_new[k]) return;
+      const Cls& C = *cls_[assigned[k]];
+      const SdPat& Pt = pats[k];
+      const LocalPattern& lp = Pt.lp;
+      if (!(C.pat.rowptr == lp.rowptr && C.pat.col == lp.col && C.pat.zero_diag == lp.zero_diag && C.pat.coord == lp.coord &&
+            C.mult == Pt.mult && C.lgptr == Pt.lgptr && C.key_extra == Pt.key_extra)) mismatch = 1;
+    }, 1);
+    HYMLS_CHECK(mismatch == 0, -3, "two different subdomain patterns share one 64-bit hash");
   }
   // ---- pass 2: symbolic analysis of every class (independent: in parallel)
   parallel_for((int64_t)(cls_.size() - first_new), [&](int64_t k) {
@@ -916,6 +930,12 @@ LevelSolver::ExtLayout LevelSolver::ext_layout(const Subdomain& S) const {
 void LevelSolver::build_schur_setup() {
   const bool dist = comm_->distributed();
   const int ng_owned = (int)gptr_.size() - 1;
+  const bool verbose = std::getenv("HYMLS_MI_VERBOSE") != nullptr;
+  double t0 = wall();
+  auto lap = [&](const char* what) {
+    if (verbose) std::fprintf(stderr, "[hymls_mi] rank %d level %d:   schur setup / %-18s %.2f s\n", comm_->rank, level_, what, wall() - t0);
+    t0 = wall();
+  };
   // ---- per class: what to keep of the (transformed) separator block
   ext_total_ = 0;
   for (auto& cp : cls_) {
@@ -954,6 +974,7 @@ void LevelSolver::build_schur_setup() {
     for (int s : my_sds_) for (int gi : hm_.sd[s].owned) gidx_of_first[hm_.sd[s].groups[gi].nodes[0]] = g++;
   }
   auto owned_sep = [&](int32_t gid) { const int l = g2l_[gid]; return (l >= 0 && pos2_[l] >= 0 && pos2_[l] < n2_) ? pos2_[l] : -1; };
+  lap("kept entries");
   // ---- records of the neighbours' subdomains that touch separators owned here
   std::vector<std::pair<int, int64_t>> contributors;   // (subdomain, base of its record in the extraction buffer)
   for (int s : my_sds_) contributors.emplace_back(s, cls_[sd_cls_[s]]->ext_base + (int64_t)sd_bidx_[s] * cls_[sd_cls_[s]]->ext_size);
@@ -1019,6 +1040,10 @@ void LevelSolver::build_schur_setup() {
   std::map<int32_t, int> bc_of_size;
   std::unordered_map<int32_t, std::pair<int, int>> block_of_key;  // first group's vsum gid -> (class, index)
   std::vector<std::vector<std::vector<int64_t>>> contrib;
+  struct BlkContrib { int cls, blk; int64_t src; };
+  std::vector<int64_t> ct_off;
+  ivec ct_vg;
+  std::vector<std::vector<BlkContrib>> ct_blk;
   for (pass = 0; pass < 2; pass++) {
   if (pass == 1) {
     for (int64_t r = 0; r < red_.n; r++) rcount[r + 1] += rcount[r];
@@ -1075,41 +1100,60 @@ void LevelSolver::build_schur_setup() {
     for (size_t c = 0; c < blocks_.size(); c++) contrib[c].resize(blocks_[c].nblk);
   }
   if (!direct_schur_) {
-    for (auto& ct : contributors) {
-      const Subdomain& S = hm_.sd[ct.first];
-      const bool local = sd_rank_[ct.first] == comm_->rank;
-      const ExtLayout L = ext_layout(S);
-      const int64_t base = ct.second;
-      ivec vg(L.ngl);
-      for (int a = 0; a < L.ngl; a++) {
-        auto it = gidx_of_first.find(S.groups[a].nodes[0]);
-        HYMLS_CHECK(dist || it != gidx_of_first.end(), -3, "separator group without owner");
-        vg[a] = it != gidx_of_first.end() ? it->second : -1;
-        if (vg[a] >= 0)
-          HYMLS_CHECK(gptr_[vg[a] + 1] - gptr_[vg[a]] == (int)S.groups[a].nodes.size(), -3, "group differs between subdomains");
-      }
-      for (int a = 0; a < L.ngl; a++)
-        if (vg[a] >= 0) {
-          if (pass == 0) rcount[vg[a] + 1] += L.ngl;
-          else for (int b = 0; b < L.ngl; b++) emit(vg[a], S.groups[b].nodes[0], base + a + (int64_t)L.ngl * b);
+    const int64_t nct = (int64_t)contributors.size();
+    if (pass == 0) {
+      // per contributor (in parallel): which owned group every one of its groups is, and its block contributions
+      ct_off.assign(nct + 1, 0);
+      for (int64_t c = 0; c < nct; c++) ct_off[c + 1] = ct_off[c] + (int64_t)hm_.sd[contributors[c].first].groups.size();
+      ct_vg.assign((size_t)ct_off[nct], -1);
+      ct_blk.assign((size_t)nct, {});
+      parallel_for(nct, [&](int64_t c) {
+        const Subdomain& S = hm_.sd[contributors[c].first];
+        const ExtLayout L = ext_layout(S);
+        const int64_t base = contributors[c].second;
+        int32_t* vg = ct_vg.data() + ct_off[c];
+        for (int a = 0; a < L.ngl; a++) {
+          auto it = gidx_of_first.find(S.groups[a].nodes[0]);
+          HYMLS_CHECK(dist || it != gidx_of_first.end(), -3, "separator group without owner");
+          vg[a] = it != gidx_of_first.end() ? it->second : -1;
+          if (vg[a] >= 0)
+            HYMLS_CHECK(gptr_[vg[a] + 1] - gptr_[vg[a]] == (int)S.groups[a].nodes.size(), -3, "group differs between subdomains");
         }
-      if (pass == 1) continue;
-      for (size_t li = 0; li < S.linked.size(); li++) {
-        if (L.blk_off[li] < 0) continue;
-        auto it = block_of_key.find(S.groups[S.linked[li][0]].nodes[0]);
-        HYMLS_CHECK(dist || it != block_of_key.end(), -3, "linked separator set without owner");
-        if (it == block_of_key.end()) continue;   // eliminated on another rank
-        BlockClass& B = blocks_[it->second.first];
-        HYMLS_CHECK(B.nb == L.blk_len[li], -3, "linked separator set differs between subdomains");
-        // same node order as the owner's block?
-        size_t t = 0;
-        for (int gi : S.linked[li])
-          for (size_t q = 1; q < S.groups[gi].nodes.size(); q++, t++)
-            HYMLS_CHECK(B.ids[(size_t)it->second.second * B.nb + t] == pos2_[g2l_[S.groups[gi].nodes[q]]], -3,
-                        "linked separator set ordered differently between subdomains");
-        contrib[it->second.first][it->second.second].push_back(base + L.blk_off[li]);
+        for (size_t li = 0; li < S.linked.size(); li++) {
+          if (L.blk_off[li] < 0) continue;
+          auto it = block_of_key.find(S.groups[S.linked[li][0]].nodes[0]);
+          HYMLS_CHECK(dist || it != block_of_key.end(), -3, "linked separator set without owner");
+          if (it == block_of_key.end()) continue;   // eliminated on another rank
+          const BlockClass& B = blocks_[it->second.first];
+          HYMLS_CHECK(B.nb == L.blk_len[li], -3, "linked separator set differs between subdomains");
+          // same node order as the owner's block?
+          size_t t = 0;
+          for (int gi : S.linked[li])
+            for (size_t q = 1; q < S.groups[gi].nodes.size(); q++, t++)
+              HYMLS_CHECK(B.ids[(size_t)it->second.second * B.nb + t] == pos2_[g2l_[S.groups[gi].nodes[q]]], -3,
+                          "linked separator set ordered differently between subdomains");
+          ct_blk[c].push_back({it->second.first, it->second.second, base + L.blk_off[li]});
+        }
+      }, 16);
+      for (int64_t c = 0; c < nct; c++) {
+        const int ngl = (int)(ct_off[c + 1] - ct_off[c]);
+        for (int a = 0; a < ngl; a++) if (ct_vg[ct_off[c] + a] >= 0) rcount[ct_vg[ct_off[c] + a] + 1] += ngl;
+        for (auto& bc : ct_blk[c]) contrib[bc.cls][bc.blk].push_back(bc.src);     // contributor (= subdomain) order
       }
-      (void)local;
+    } else {
+      // fill (in parallel): every (contributor, owned row group) reserves its ngl slots of the row with one atomic add;
+      // the rows are sorted afterwards, so the order of arrival does not matter
+      parallel_for(nct, [&](int64_t c) {
+        const Subdomain& S = hm_.sd[contributors[c].first];
+        const int ngl = (int)(ct_off[c + 1] - ct_off[c]);
+        const int64_t base = contributors[c].second;
+        const int32_t* vg = ct_vg.data() + ct_off[c];
+        for (int a = 0; a < ngl; a++) {
+          if (vg[a] < 0) continue;
+          int64_t o = __atomic_fetch_add(&rfill[vg[a]], (int64_t)ngl, __ATOMIC_RELAXED);
+          for (int b = 0; b < ngl; b++) keys[o++] = ((uint64_t)S.groups[b].nodes[0] << 33) | (uint64_t)(base + a + (int64_t)ngl * b);
+        }
+      }, 16);
     }
   }
   }  // passes
@@ -1149,6 +1193,7 @@ void LevelSolver::build_schur_setup() {
     d_vrhs_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
     d_vsol_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
   }
+  lap("contributions");
   // buckets -> CSR pattern (columns = gids) with pull lists: sort every row (column gid, then source position)
   const int64_t nr = red_.n;
   red_.rowptr.assign(nr + 1, 0);
@@ -1181,6 +1226,7 @@ void LevelSolver::build_schur_setup() {
     C.d_lgptr = dev::upload(C.lgptr);
     C.d_tvloc = dev::upload(C.tvloc);
   }
+  lap("pull lists");
   // ---- tables of the fused interior solve (classes whose vectors fit in LDS)
   constexpr int32_t LDS_CAP = 12288;  // doubles (96 KiB)
   std::vector<dev::PlanD> plans;
@@ -1210,6 +1256,7 @@ void LevelSolver::build_schur_setup() {
                  comm_->rank, level_, n_fsubs_, my_sds_.size(), fused_lds_, fused_lds_ * 8.0 / 1024);
   d_fplans_ = dev::upload(plans);
   d_fsubs_ = dev::upload(subs);
+  lap("class uploads");
   // ---- merged level solve for the classes that do not fit (large subdomains of the coarser levels):
   // one launch per tree level and sweep for all of them together
   cls_merged_.assign(cls_.size(), 0);

@@ -26,6 +26,13 @@ int64_t Comm::allsum(int64_t v) const {
   return t;
 }
 
+void Comm::allsum(std::vector<double>& v) const {
+  if (!distributed() || v.empty()) return;
+  std::vector<double> all = allgather(v);
+  const size_t m = v.size();
+  for (size_t i = 0; i < m; i++) { double s = 0.0; for (int q = 0; q < size; q++) s += all[(size_t)q * m + i]; v[i] = s; }
+}
+
 static double* grow(const Comm& c, double*& arena, int64_t& cap, int64_t need) {
   if (need <= cap && arena) return arena;
   HYMLS_CHECK(c.alloc != nullptr, -2, "sharded run without an arena allocator (hymls_mi_set_comm)");
@@ -76,14 +83,18 @@ void Exchange::forward(const double* src, double* dst) const {
   if (nrecv) dev::scatter(nrecv, d_ridx, rb, dst);
 }
 
-void Exchange::backward(const double* src, double* dst) const {
+void Exchange::backward(const double* src, double* dst, bool add) const {
   if (!any) return;
   double* sb = comm->send_arena(nrecv);
   double* rb = comm->recv_arena(nsend);
   if (nrecv) dev::gather(nrecv, d_ridx, src, sb);
   const int ierr = comm->alltoallv(comm->ctx, sb, rcnt.data(), rb, scnt.data(), (int32_t)sizeof(double), 1);
   HYMLS_CHECK(ierr == 0, -3, "device all-to-all failed in the transport callback");
-  if (nsend) dev::scatter(nsend, d_sidx, rb, dst);
+  if (!nsend) return;
+  if (!add) { dev::scatter(nsend, d_sidx, rb, dst); return; }
+  // peer by peer (a position may get contributions from several peers): fixed order of the additions
+  int64_t off = 0;
+  for (int q = 0; q < comm->size; q++) { dev::scatter_add(scnt[q], d_sidx + off, rb + off, dst); off += scnt[q]; }
 }
 
 }  // namespace hymls

@@ -68,6 +68,8 @@ struct Comm {
     return all;
   }
   int64_t allsum(int64_t v) const;
+  // element-wise sum over the ranks, added in rank order (the same bits on every rank)
+  void allsum(std::vector<double>& v) const;
 
   // ---- device arenas (grown on demand; shared by every exchange of this communicator)
   double* send_arena(int64_t doubles) const;
@@ -96,7 +98,7 @@ struct Exchange {
   void build(const Comm& c, const std::vector<std::vector<int64_t>>& want_keys, const std::vector<ivec>& want_dst,
              const std::function<int32_t(int64_t)>& resolve);
   void forward(const double* src, double* dst) const;    // dst[ridx] <- peer src[sidx]
-  void backward(const double* src, double* dst) const;   // reverse direction: dst[sidx] <- peer src[ridx]
+  void backward(const double* src, double* dst, bool add = false) const;   // reverse direction: dst[sidx] <- (or +=) peer src[ridx]
 };
 
 }  // namespace hymls

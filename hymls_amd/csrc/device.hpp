@@ -104,6 +104,7 @@ struct BatchD {
 // ---- vector kernels
 void gather(int64_t n, const int32_t* idx, const double* src, double* dst);      // dst[i] = src[idx[i]]
 void scatter(int64_t n, const int32_t* idx, const double* src, double* dst);     // dst[idx[i]] = src[i]
+void scatter_add(int64_t n, const int32_t* idx, const double* src, double* dst); // dst[idx[i]] += src[i] (atomic: idx may repeat)
 void axpby(int64_t n, double a, const double* x, double b, double* y);           // y = a x + b y
 void scale_copy(int64_t n, double a, const double* x, double* y);                // y = a x
 // y = alpha * A x + beta * y, CSR with 32-bit indices

@@ -173,6 +173,13 @@ void scatter(int64_t n, const int32_t* idx, const double* src, double* dst) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, 256, 8192)), dim3(256), 0, g_stream, n, idx, src, dst); launch_check();
 }
+__global__ void k_scatter_add(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ src, double* __restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&dst[idx[i]], src[i]);
+}
+void scatter_add(int64_t n, const int32_t* idx, const double* src, double* dst) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_scatter_add, dim3(nblocks(n, 256, 65536)), dim3(256), 0, g_stream, n, idx, src, dst); launch_check();
+}
 void axpby(int64_t n, double a, const double* x, double b, double* y) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_axpby, dim3(nblocks(n, 256, 8192)), dim3(256), 0, g_stream, n, a, x, b, y); launch_check();

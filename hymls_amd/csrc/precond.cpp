@@ -1414,6 +1414,7 @@ void LevelSolver::build_handoff(const ivec& next_owned) {
   const int64_t nown = red_.n;
   xch_down_.build(*comm_, want, dst, [nown](int64_t k) { return k < nown ? (int32_t)k : -1; });
   dev::free(d_nrhs_); dev::free(d_nsol_);
+  n_next_owned_ = (int64_t)next_owned.size();
   d_nrhs_ = (double*)dev::alloc(std::max<size_t>(1, next_owned.size()) * sizeof(double));
   d_nsol_ = (double*)dev::alloc(std::max<size_t>(1, next_owned.size()) * sizeof(double));
 }
@@ -1474,7 +1475,7 @@ void LevelSolver::compute() {
     next_.reset();
     next_level_ = nullptr;
     next_is_direct_ = true;
-    if (dist) next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_));
+    if (dist) next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, nullptr, nullptr, nullptr, bm_ > 0));
     else next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &sep_sd_ptr_, &sep_sd_, &sd_center_, bm_ > 0));
     build_handoff(next_gids);
     set_next_border();
@@ -1530,7 +1531,7 @@ void LevelSolver::compute() {
     next_level_ = nullptr;
     next_is_direct_ = true;
     if (dist) {
-      next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_));
+      next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, nullptr, nullptr, nullptr, bm_ > 0));
     } else {
       ivec cp(1, 0), cl;
       for (int g = 0; g < ng; g++) {
@@ -1686,7 +1687,6 @@ void LevelSolver::build_matvec() {
 // (BorderedOperator interface of HYMLS::Preconditioner, reference src/HYMLS_Preconditioner.cpp:519-588,844-918,
 // 930-1070 and of the SchurPreconditioner, src/HYMLS_SchurPreconditioner.cpp:631-664,1517-1617)
 void LevelSolver::set_border(int m, const double* dV, const double* dW, const double* C) {
-  HYMLS_CHECK(!comm_->distributed() || m <= 0, -99, "bordered systems are not implemented for sharded runs");
   HYMLS_CHECK(initialized_, -1, "SetBorder needs an initialized preconditioner");
   void* ptrs[] = {d_bVu_, d_bWu_, d_bW1_, d_bQ1_, d_bSV_, d_bSW_, d_bNV_, d_bNW_, d_btmp_};
   for (void* q : ptrs) dev::free(q);
@@ -1701,11 +1701,12 @@ void LevelSolver::set_border(int m, const double* dV, const double* dW, const do
   dev::d2d(d_bWu_, dW ? dW : dV, n * m * sizeof(double));
   bC_.assign((size_t)m * m, 0.0);
   if (C) bC_.assign(C, C + (size_t)m * m);
+  // (sharded: Q1 columns carry the halo of the neighbours' interior layer behind the n1 local entries)
   d_bW1_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)n1_ * m) * sizeof(double));
-  d_bQ1_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)n1_ * m) * sizeof(double));
+  d_bQ1_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)(n1_ + ngi_) * m) * sizeof(double));
   d_bSV_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)n2_ * m) * sizeof(double));
   d_bSW_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)n2_ * m) * sizeof(double));
-  d_btmp_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)std::max(n1_, n2_)) * sizeof(double));
+  d_btmp_ = (double*)dev::alloc(std::max<size_t>(1, (size_t)std::max(n1_ + ngi_, n2_ + ngs_)) * sizeof(double));
   const size_t ng = vs_.size();
   d_bNV_ = (double*)dev::alloc(std::max<size_t>(1, ng * m) * sizeof(double));
   d_bNW_ = (double*)dev::alloc(std::max<size_t>(1, ng * m) * sizeof(double));
@@ -1752,7 +1753,7 @@ void LevelSolver::compute_border() {
   for (int j = 0; j < m; j++) {
     const double* vu = d_bVu_ + (size_t)j * (n1_ + n2_);
     const double* wu = d_bWu_ + (size_t)j * (n1_ + n2_);
-    double* q1 = d_bQ1_ + (size_t)j * n1_;
+    double* q1 = d_bQ1_ + (size_t)j * (n1_ + ngi_);
     double* w1 = d_bW1_ + (size_t)j * n1_;
     double* sv = d_bSV_ + (size_t)j * n2_;
     double* sw = d_bSW_ + (size_t)j * n2_;
@@ -1761,14 +1762,28 @@ void LevelSolver::compute_border() {
     dev::gather(n1_, d_inperm_, wu, w1);
     dev::gather(n2_, d_inperm_ + n1_, wu, sw);
     interior_solve(q1);                                                               // Q1 = A11 \ V1
+    xch_int_.forward(q1, q1);                                                         // (halo of the neighbours' interior layer)
     dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, q1, sv, -1.0, 1.0);            // SV = V2 - A21 Q1
     dev::d2d(d_btmp_, w1, (size_t)n1_ * sizeof(double));
     interior_solve_transposed(d_btmp_);                                               // A11' \ W1
-    dev::spmv(n2_, d_a12t_row_, d_a12t_col_, d_a12t_val_, d_btmp_, sw, -1.0, 1.0);    // SW = W2 - A12' (...)
+    if (!comm_->distributed()) {
+      dev::spmv(n2_, d_a12t_row_, d_a12t_col_, d_a12t_val_, d_btmp_, sw, -1.0, 1.0);  // SW = W2 - A12' (...)
+    } else {
+      // rows of A12' for separators owned elsewhere are partial sums that belong to their owners
+      double* t2 = d_t2_;                      // n2 + ngs entries, free during Compute
+      dev::spmv(n2_ + ngs_, d_a12t_row_, d_a12t_col_, d_a12t_val_, d_btmp_, t2, 1.0, 0.0);
+      xch_sep_.backward(t2, t2, true);
+      dev::axpby(n2_, -1.0, t2, 1.0, sw);
+    }
   }
   bSC_ = bC_;
-  for (int j = 0; j < m; j++)
-    for (int i = 0; i < m; i++) bSC_[i + (size_t)m * j] -= dev::dot(n1_, d_bW1_ + (size_t)i * n1_, d_bQ1_ + (size_t)j * n1_);
+  {
+    dvec d((size_t)m * m);
+    for (int j = 0; j < m; j++)
+      for (int i = 0; i < m; i++) d[i + (size_t)m * j] = dev::dot(n1_, d_bW1_ + (size_t)i * n1_, d_bQ1_ + (size_t)j * (n1_ + ngi_));
+    comm_->allsum(d);
+    for (size_t k = 0; k < d.size(); k++) bSC_[k] -= d[k];
+  }
   if (!direct_schur_) {
     const int ng = (int)vs_.size();
     for (int j = 0; j < m; j++) {
@@ -1784,20 +1799,44 @@ void LevelSolver::compute_border() {
 void LevelSolver::set_next_border() {
   if (!next_) return;
   if (bm_ == 0) { next_->set_border(0, nullptr, nullptr, nullptr); return; }
-  if (direct_schur_) next_->set_border(bm_, d_bSV_, d_bSW_, bSC_.data());
-  else next_->set_border(bm_, d_bNV_, d_bNW_, bSC_.data());
+  const double* v = direct_schur_ ? d_bSV_ : d_bNV_;
+  const double* w = direct_schur_ ? d_bSW_ : d_bNW_;
+  if (!comm_->distributed()) { next_->set_border(bm_, v, w, bSC_.data()); return; }
+  // sharded: the border rows travel to the next level's layout like every right-hand side (hand-off exchange)
+  const size_t nown = (size_t)red_.n, nn = (size_t)std::max<int64_t>(n_next_owned_, 1);
+  double* nv = (double*)dev::alloc(nn * bm_ * sizeof(double));
+  double* nw = (double*)dev::alloc(nn * bm_ * sizeof(double));
+  for (int j = 0; j < bm_; j++) {
+    xch_down_.forward(v + nown * j, nv + (size_t)n_next_owned_ * j);
+    xch_down_.forward(w + nown * j, nw + (size_t)n_next_owned_ * j);
+  }
+  next_->set_border(bm_, nv, nw, bSC_.data());
+  dev::free(nv); dev::free(nw);
+}
+
+void LevelSolver::next_apply_bordered(const double* rhs, const double* T, double* sol, double* S) {
+  if (!comm_->distributed()) { next_->apply_inverse_bordered(rhs, T, sol, S); return; }
+  xch_down_.forward(rhs, d_nrhs_);
+  next_->apply_inverse_bordered(d_nrhs_, T, d_nsol_, S);
+  if (next_is_direct_) {
+    if (red_.n) dev::d2d(sol, d_nsol_ + glob_row_off_[comm_->rank], (size_t)red_.n * sizeof(double));
+  } else {
+    xch_down_.backward(d_nsol_, sol);
+  }
 }
 
 void LevelSolver::schur_apply_bordered(double* rhs2, const double* q, double* x2, double* S) {
-  if (direct_schur_) { next_->apply_inverse_bordered(rhs2, q, x2, S); return; }
+  if (direct_schur_) { next_apply_bordered(rhs2, q, x2, S); return; }
   const int ng = (int)vs_.size(), m = bm_;
   dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);
   dev::zero(x2, (size_t)n2_ * sizeof(double));                          // V-sum entries are zero in W'(M11 \ f1)
   dev::blocks_apply_all(n_blk_apply_, d_blka_, blk_max_nb_, rhs2, x2);
   dvec tc(m);
-  for (int j = 0; j < m; j++) tc[j] = q[j] - dev::dot(n2_, d_bSW_ + (size_t)j * n2_, x2);
+  for (int j = 0; j < m; j++) tc[j] = dev::dot(n2_, d_bSW_ + (size_t)j * n2_, x2);
+  comm_->allsum(tc);
+  for (int j = 0; j < m; j++) tc[j] = q[j] - tc[j];
   dev::gather(ng, d_vs_, rhs2, d_vrhs_);
-  next_->apply_inverse_bordered(d_vrhs_, tc.data(), d_vsol_, S);
+  next_apply_bordered(d_vrhs_, tc.data(), d_vsol_, S);
   dev::scatter(ng, d_vs_, d_vsol_, x2);
   dev::ot_apply(ng, d_gptr_, d_otw_, x2);
 }
@@ -1811,14 +1850,18 @@ void LevelSolver::apply_inverse_bordered(const double* b, const double* T, doubl
   dev::gather(n1_, d_inperm_, b, z1);
   dev::gather(n2_, d_inperm_ + n1_, b, z2);
   interior_solve(z1);                                                               // x1 = A11 \ b1
+  xch_int_.forward(z1, z1);
   dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1, z2, -1.0, 1.0);            // b2 - A21 x1
   dvec q(m);
-  for (int j = 0; j < m; j++) q[j] = T[j] - dev::dot(n1_, d_bW1_ + (size_t)j * n1_, z1);   // T - W1' x1
+  for (int j = 0; j < m; j++) q[j] = dev::dot(n1_, d_bW1_ + (size_t)j * n1_, z1);
+  comm_->allsum(q);
+  for (int j = 0; j < m; j++) q[j] = T[j] - q[j];                                   // T - W1' x1
   schur_apply_bordered(z2, q.data(), d_t2_, S);
+  xch_sep_.forward(d_t2_, d_t2_);
   dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0);
   interior_solve(d_t1_);
   dev::axpby(n1_, -1.0, d_t1_, 1.0, z1);                                            // x1 -= A11 \ (A12 x2)
-  for (int j = 0; j < m; j++) dev::axpby(n1_, -S[j], d_bQ1_ + (size_t)j * n1_, 1.0, z1);   // x1 -= Q1 S
+  for (int j = 0; j < m; j++) dev::axpby(n1_, -S[j], d_bQ1_ + (size_t)j * (n1_ + ngi_), 1.0, z1);   // x1 -= Q1 S
   dev::scatter(n1_, d_inperm_, z1, x);
   dev::scatter(n2_, d_inperm_ + n1_, d_t2_, x);
 }

@@ -158,6 +158,8 @@ class LevelSolver : public Operator {
   void compute_border();
   void set_next_border();
   void schur_apply_bordered(double* rhs2, const double* q, double* x2, double* S);
+  void next_apply_bordered(const double* rhs, const double* T, double* sol, double* S);
+  int64_t n_next_owned_ = 0;   // rows of the next level's layout on this rank (sharded hand-off)
   // border (one rank only): user-layout copies, their interior / separator parts, A11^{-1} V1, transformed Schur border
   int bm_ = 0;
   dvec bC_, bSC_;

@@ -119,8 +119,8 @@ int hymls_mi_apply_inverse(hymls_mi_t* h, const double* B, int64_t ldb,
  * src/HYMLS_Preconditioner.cpp:844-918 SetBorder, :519-588 ComputeBorder, :930-1070 bordered ApplyInverse)
  * [K V; W' C] [x; s] = [b; t].  V, W: host arrays n x m, column-major with leading dimensions ldv/ldw
  * (W == NULL: W = V), C: m x m column-major (NULL: zero).  m == 0 or V == NULL removes the border.  Call after
- * Initialize; Compute has to be called afterwards (as in the reference).  One rank only (returns -99 on a
- * sharded handle). */
+ * Initialize; Compute has to be called afterwards (as in the reference).  On a sharded handle every rank passes
+ * the rows it owns (hymls_mi_owned_rows); T and S are the same on every rank. */
 int hymls_mi_set_border(hymls_mi_t* h, int m, const double* V, int64_t ldv, const double* W, int64_t ldw,
                         const double* C);
 /* ApplyInverse(B, T, X, S): B, X one vector (host or device as on_device says), T, S host arrays of m doubles.

@@ -72,19 +72,33 @@ def main():
         rhs_loc = P.MatVec(x_ex[owned])
         xs_loc = S.ApplyInverse(torch.from_numpy(rhs_loc.copy())).numpy()
         its_sh = S.getNumIter()
+    # bordered system on the sharded handle (HYMLS_TEST_BORDER=1): every rank passes its rows of V and W
+    xb_loc, sb = None, None
+    if os.environ.get("HYMLS_TEST_BORDER"):
+        rngb = np.random.default_rng(17)
+        Vg, Wg, Cg = rngb.uniform(-1, 1, (N, 2)), rngb.uniform(-1, 1, (N, 2)), rngb.uniform(-1, 1, (2, 2))
+        tb = rngb.uniform(-1, 1, 2)
+        P.SetBorder(Vg[owned], Wg[owned], Cg)
+        P.Compute()
+        xb_loc, sb = P.ApplyInverseBordered(b[owned], tb)
+        P.SetBorder(None)
+        P.Compute()
     parts = [None] * world
-    dist.all_gather_object(parts, (owned, x_loc, float(np.abs(x_loc2 - x_loc).max()), float(np.abs(x_loc3 - x_loc).max()), kx, xs_loc))
+    dist.all_gather_object(parts, (owned, x_loc, float(np.abs(x_loc2 - x_loc).max()), float(np.abs(x_loc3 - x_loc).max()), kx, xs_loc, xb_loc, sb))
     ok = True
     if rank == 0:
         x = np.full(N, np.nan)
         cover = np.zeros(N, np.int64)
         kxg = np.zeros(N); xsg = np.zeros(N)
-        for o, xl, _, _, kxl, xsl in parts:
+        xbg = np.zeros(N)
+        for o, xl, _, _, kxl, xsl, xbl, _sb in parts:
             x[o] = xl
             cover[o] += 1
             kxg[o] = kxl
             if xsl is not None:
                 xsg[o] = xsl
+            if xbl is not None:
+                xbg[o] = xbl
         K = hymls_amd.generate_matrix(eq, nx, ny, nz, a=a, lib=lib)
         tv = hymls_amd.generate_testvector(*K, lib=lib)
         P0 = hymls_amd.Preconditioner(K, prm, testVector=tv, lib=lib)
@@ -101,13 +115,22 @@ def main():
             S0.ApplyInverse(torch.from_numpy(rhs.copy()))
             its_one = S0.getNumIter()
             sol_res = float(np.linalg.norm(rhs - Ks @ xsg) / np.linalg.norm(rhs))
-        res = {"world": world, "cover_ok": bool((cover == 1).all()), "rel_err": err, "matvec_err": mv_err,
+        border_err = 0.0
+        if parts[0][6] is not None:
+            P0.SetBorder(Vg, Wg, Cg)
+            P0.Compute()
+            xb0, sb0 = P0.ApplyInverseBordered(b, tb)
+            border_err = max(float(np.linalg.norm(xbg - xb0) / np.linalg.norm(xb0)),
+                             max(float(np.abs(p[7] - sb0).max() / max(np.abs(sb0).max(), 1e-300)) for p in parts))
+            P0.SetBorder(None)
+            P0.Compute()
+        res = {"world": world, "cover_ok": bool((cover == 1).all()), "rel_err": err, "matvec_err": mv_err, "border_err": border_err,
                "krylov_its_sharded": its_sh, "krylov_its_one_rank": its_one, "krylov_residual": sol_res,
                "repeat_diff": max(p[2] for p in parts), "recompute_diff": max(p[3] for p in parts),
                "levels": P0.level_sizes(), "levels_sharded": P.level_sizes()}
         print("DIST_RESULT " + json.dumps(res), flush=True)
         ok = (res["cover_ok"] and err < 1e-9 and res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12 and mv_err < 1e-13
-              and abs(its_sh - its_one) <= 1 and sol_res < 1e-6)
+              and abs(its_sh - its_one) <= 1 and sol_res < 1e-6 and border_err < 1e-9)
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

@@ -47,6 +47,7 @@ double timer_stop(int id) { return std::chrono::duration<double>(std::chrono::st
 
 void gather(int64_t n, const int32_t* idx, const double* src, double* dst) { for (int64_t i = 0; i < n; i++) dst[i] = src[idx[i]]; }
 void scatter(int64_t n, const int32_t* idx, const double* src, double* dst) { for (int64_t i = 0; i < n; i++) dst[idx[i]] = src[i]; }
+void scatter_add(int64_t n, const int32_t* idx, const double* src, double* dst) { for (int64_t i = 0; i < n; i++) dst[idx[i]] += src[i]; }
 void axpby(int64_t n, double a, const double* x, double b, double* y) { for (int64_t i = 0; i < n; i++) y[i] = a * x[i] + b * y[i]; }
 void scale_copy(int64_t n, double a, const double* x, double* y) { for (int64_t i = 0; i < n; i++) y[i] = a * x[i]; }
 void spmv(int32_t nrows, const int32_t* rp, const int32_t* col, const double* val, const double* x, double* y,

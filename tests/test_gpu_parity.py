@@ -185,9 +185,9 @@ def test_sharded_matches_single_gpu(gpu_lib, world, args):
     ranks on one device, so the transport stages through gloo here; on a multi-GPU node the same callbacks
     run dist.all_to_all_single on RCCL).  Assembled sharded ApplyInverse == one-rank ApplyInverse."""
     from test_sharded import run_worker
-    res = run_worker(world, args, "gpu", 29540 + world, timeout=900)
+    res = run_worker(world, args, "gpu", 29540 + world, timeout=900, env_extra={"HYMLS_TEST_BORDER": "1"})
     assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
-    assert res["rel_err"] < 1e-10
+    assert res["rel_err"] < 1e-10 and res["border_err"] < 1e-9        # plain and bordered ApplyInverse
     assert res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12
 
 

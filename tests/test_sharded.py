@@ -65,3 +65,15 @@ def test_sharded_host_exchange_in_rounds(hostsim_lib):
     res = run_worker(4, ("Laplace", 16, 16, 8, 4, 1, -1, "Cartesian"), "hostsim", 29575,
                      env_extra={"HYMLS_MI_HOST_CHUNK_BYTES": "1024"})
     assert res["cover_ok"] and res["rel_err"] < 1e-12 and res["matvec_err"] < 1e-13
+
+
+@pytest.mark.parametrize("world,eq,nx,ny,nz,sx,levels,cx,part", [
+    (2, "Stokes-C", 16, 8, 8, 4, 0, -1, "Skew Cartesian"),
+    (4, "Stokes-C", 16, 16, 8, 4, 1, -1, "Skew Cartesian"),
+    (8, "Laplace", 16, 16, 16, 4, 2, 2, "Cartesian"),
+])
+def test_sharded_bordered_matches_one_rank(hostsim_lib, world, eq, nx, ny, nz, sx, levels, cx, part):
+    """[K V; W' C] on a sharded handle: every rank passes its rows of V and W; the border scalars are all-reduced, the
+    border of the Schur system travels with the halo / hand-off exchanges.  Same (X, S) as on one rank."""
+    res = run_worker(world, (eq, nx, ny, nz, sx, levels, cx, part), "hostsim", 29580 + world, env_extra={"HYMLS_TEST_BORDER": "1"})
+    assert res["cover_ok"] and res["rel_err"] < 1e-12 and res["border_err"] < 1e-10

@@ -296,3 +296,16 @@ def test_reference_driven_cavity_2d_gpu(gpu_lib, re, part, levels, its_max):
     """the reference's 2D driven-cavity Jacobian at Re 1000 (its own test data) on the GPU path"""
     from test_hostsim_parity import cavity2d_case
     cavity2d_case(gpu_lib, re, part, levels, its_max)
+
+
+@pytest.mark.gpu
+def test_c_abi_from_plain_c(gpu_lib, tmp_path):
+    """include/hymls_mi.h from a C program (gcc, no Python / torch in the process): create, set matrix, Compute,
+    ApplyInverse with host buffers, error code before Compute, exactness of the one-level method."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "capi_smoke")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "capi", "capi_smoke.c"), "-o", exe,
+                           "-L", os.path.join(root, "hymls_amd"), "-lhymls_mi", "-Wl,-rpath," + os.path.join(root, "hymls_amd"), "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "CAPI_SMOKE" in out.stdout, out.stdout + out.stderr

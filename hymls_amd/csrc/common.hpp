@@ -9,6 +9,9 @@
 #include <algorithm>
 #include <numeric>
 #include <cmath>
+#include <thread>
+#include <mutex>
+#include <exception>
 
 namespace hymls {
 
@@ -56,5 +59,22 @@ struct Params {
     return q;
   }
 };
+
+// static chunks over [0, n) on up to 16 host threads (setup-time integer work only)
+template <class Fn>
+void parallel_for(int64_t n, Fn fn, int64_t grain = 256) {
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / grain}));
+  if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+  std::vector<std::thread> th;
+  std::exception_ptr err = nullptr;
+  std::mutex mu;
+  for (int t = 0; t < nt; t++)
+    th.emplace_back([&, t] {
+      try { for (int64_t i = n * t / nt; i < n * (t + 1) / nt; i++) fn(i); }
+      catch (...) { std::lock_guard<std::mutex> lk(mu); err = std::current_exception(); }
+    });
+  for (auto& x : th) x.join();
+  if (err) std::rethrow_exception(err);
+}
 
 }  // namespace hymls

@@ -138,13 +138,15 @@ HierMap build_hiermap(const Params& p, const std::vector<char>* present, const s
   HYMLS_CHECK(h.ngid < (int64_t)1 << 31, -2, "more than 2^31 unknowns need 64-bit GIDs");
   const int nsd = num_subdomains(p);
   h.sd.resize(nsd);
-  std::vector<char> seen(h.ngid, 0);  // first gid of every group already owned
-  for (int s = 0; s < nsd; s++) {
-    if (cand && !(*cand)[s]) continue;
+  // groups of every (candidate) subdomain: independent, in parallel; ownership ("first subdomain that lists the group")
+  // afterwards in subdomain order
+  if (nsd > 0) { ivec it; std::vector<Group> gr; if (p.partitioner != 0) skew_get_groups(p, 0, it, gr); }   // build the template once
+  parallel_for(nsd, [&](int64_t s) {
+    if (cand && !(*cand)[s]) return;
     Subdomain& S = h.sd[s];
     std::vector<Group> raw;
-    if (p.partitioner == 0) cartesian_get_groups(p, s, S.interior, raw);
-    else skew_get_groups(p, s, S.interior, raw);
+    if (p.partitioner == 0) cartesian_get_groups(p, (int)s, S.interior, raw);
+    else skew_get_groups(p, (int)s, S.interior, raw);
     auto filt = [&](ivec& v) {
       std::sort(v.begin(), v.end());
       if (present) v.erase(std::remove_if(v.begin(), v.end(), [&](int32_t g) { return !(*present)[g]; }), v.end());
@@ -154,6 +156,11 @@ HierMap build_hiermap(const Params& p, const std::vector<char>* present, const s
       filt(g.nodes);
       if (!g.nodes.empty()) S.groups.push_back(std::move(g));
     }
+  }, 4);
+  std::vector<char> seen(h.ngid, 0);  // first gid of every group already owned
+  for (int s = 0; s < nsd; s++) {
+    if (cand && !(*cand)[s]) continue;
+    Subdomain& S = h.sd[s];
     for (int gi = 0; gi < (int)S.groups.size(); gi++) {
       const int32_t first = S.groups[gi].nodes[0];
       if (!seen[first]) { seen[first] = 1; S.owned.push_back(gi); }

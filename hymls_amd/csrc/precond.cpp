@@ -28,23 +28,6 @@ inline void gid_coord(const Params& p, int32_t gid, int32_t* c) {
   c[0] = 2 * i + (vt == VT_U); c[1] = 2 * j + (vt == VT_V); c[2] = 2 * k + (vt == VT_W);
 }
 
-// static chunks over [0, n) on up to 16 host threads (setup-time integer work only)
-template <class Fn>
-void parallel_for(int64_t n, Fn fn, int64_t grain = 256) {
-  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / grain}));
-  if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
-  std::vector<std::thread> th;
-  std::exception_ptr err = nullptr;
-  std::mutex mu;
-  for (int t = 0; t < nt; t++)
-    th.emplace_back([&, t] {
-      try { for (int64_t i = n * t / nt; i < n * (t + 1) / nt; i++) fn(i); }
-      catch (...) { std::lock_guard<std::mutex> lk(mu); err = std::current_exception(); }
-    });
-  for (auto& x : th) x.join();
-  if (err) std::rethrow_exception(err);
-}
-
 constexpr int LEAF_SIZE = 24;
 constexpr int MAX_WIDTH = 256;
 constexpr int MAX_WIDTH_COARSE = 256;  // wider supernodes take the piece-wise big-front path
@@ -960,11 +943,11 @@ void LevelSolver::build_schur_setup() {
     ext_total_ += C.ext_size * (int64_t)C.lu.members.size();
     // test vector at the separators of every member
     C.tvloc.assign((size_t)nS * C.lu.members.size(), 1.0);
-    for (size_t b = 0; b < C.lu.members.size(); b++) {
+    parallel_for((int64_t)C.lu.members.size(), [&](int64_t b) {
       const Subdomain& S = hm_.sd[C.lu.members[b]];
       size_t t = 0;
-      for (auto& g : S.groups) for (int32_t x : g.nodes) C.tvloc[b * nS + t++] = tv_[g2l_[x]];
-    }
+      for (auto& g : S.groups) for (int32_t x : g.nodes) C.tvloc[(size_t)b * nS + t++] = tv_[g2l_[x]];
+    }, 64);
   }
   ext_recv_base_ = ext_total_;
   // owned group lookup by first gid

@@ -62,6 +62,9 @@ def cpu_baseline(n, sx, levels, seconds_budget=30.0):
                       "Number of Levels=%d; %d applies of %.3f s after a %.1f s setup" % (n, A.shape[0], sx, levels, reps, t_apply, t_setup)}
 
 
+PROBLEM = {"stokes": "Stokes", "darcy": "Darcy", "cavity": "Cavity"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +73,10 @@ def main():
     ap.add_argument("--grid", dest="n", type=int, default=256, help="global grid size per direction")
     ap.add_argument("--sx", type=int, default=8)
     ap.add_argument("--levels", type=int, default=2, help="XML 'Number of Levels' (2 = the 3-level method)")
+    ap.add_argument("--problem", choices=["stokes", "darcy", "cavity"], default="stokes",
+                    help="input matrix: GaleriExt Stokes3D (configs[1], [2]), GaleriExt Darcy3D (configs[4]), "
+                         "Navier-Stokes-like Jacobian at --re (configs[3]; synthesised, see oracle/galeri.py:oseen3d)")
+    ap.add_argument("--re", type=float, default=1000.0, help="Reynolds number of --problem cavity")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies instead of the sharded problem")
     ap.add_argument("--krylov", action="store_true",
                     help="after the timed region: solve K x = b (b = K x_ex) with right-preconditioned GMRES on the device "
@@ -89,8 +96,20 @@ def main():
                          "numbers produced this way are meaningless and are marked as such")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU now, before anything touches the GPU
+        # (never re-launch from a process that has initialised HIP), and leave with the launcher's exit code
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29533")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world and not args.hostsim:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a %d-GPU number as the %d-GPU point\n"
+                         % (args.gpus, world, world, args.gpus))
+        sys.exit(2)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import hymls_amd
     if args.hostsim:
@@ -120,12 +139,14 @@ def main():
     sharded = (world > 1 and not args.replicas) or args.force_sharded
     note = None
     if sharded:
-        # self-test of the transport on this backend (uneven all-to-all on the library's stream); if any rank
-        # fails, every rank falls back to replicas and the line says so
+        # self-test of the transport on this backend (uneven all-to-all on the library's stream); a failure ends the
+        # run with a non-zero exit code: N replicas under the sharded metric would inflate the number
         from hymls_amd.dist import TorchComm, rank_grid, transport_selftest
         err = transport_selftest(dev, backend)
         if err:
-            sharded, note = False, "sharded transport self-test failed (%s): replicas" % err
+            sys.stderr.write("bench.py: sharded transport self-test failed on rank %d (%s); no fallback\n" % (rank, err))
+            dist.destroy_process_group()
+            sys.exit(3)
     levels = args.levels
     if sharded:
         px, py, pz = rank_grid(world)
@@ -136,7 +157,7 @@ def main():
         P = hymls_amd.Preconditioner(None, prm, device=local_rank, lib=lib, comm=comm, rank_grid=(px, py, pz))
         t0 = time.time()
         req = P.RequiredRows()
-        rows = hymls_amd.generate_rows("Stokes-C", nx, ny, nz, req, a=float(nx * nx), lib=lib)
+        rows = hymls_amd.generate_problem(PROBLEM[args.problem], nx, ny, nz, re=args.re, gids=req, lib=lib)
         P.SetMatrixRows(req, rows)
         P.SetTestVector(hymls_amd.generate_testvector_rows(req, *rows))
         del rows
@@ -147,7 +168,7 @@ def main():
         N_global = nx * ny * nz * 4
     else:
         nx = ny = nz = n
-        rp, ci, va = hymls_amd.generate_matrix("Stokes-C", n, n, n, lib=lib)
+        rp, ci, va = hymls_amd.generate_problem(PROBLEM[args.problem], n, n, n, re=args.re, lib=lib)
         tv = hymls_amd.generate_testvector(rp, ci, va, lib=lib)
         prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": n, "ny": n, "nz": n},
                "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
@@ -189,7 +210,7 @@ def main():
     t_phase = [P.last_apply_seconds(i) for i in range(5)]   # averages over the timed steps
     P.set_profiling(False)
     assert bool(np.isfinite(x).all() if args.hostsim else torch.isfinite(x).all()), "ApplyInverse produced non-finite values"
-    bytes_all = [P.apply_bytes(i) for i in range(6)]
+    bytes_all = [P.apply_bytes(i) for i in range(9)]
     bytes_rank0 = list(bytes_all)
     if world > 1:   # algorithmic bytes of the whole job = sum over the ranks
         t = torch.tensor(bytes_all, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -226,7 +247,8 @@ def main():
         # U-side) + the interior vector in and out.
         lv = P.level_sizes()
         n1 = (lv[0][1] - lv[0][2]) / (world if sharded else 1)   # interior unknowns per GPU
-        bytes_launch = bytes_rank0[1] / 2.0 + 16.0 * n1          # this rank's launch
+        # (the smaller of the stored footprint and the sparse-equivalent nnz(L+U) x 12 B + 24 B per unknown)
+        bytes_launch = min(bytes_rank0[1], bytes_rank0[6]) / 2.0 + 16.0 * n1          # this rank's launch
         t_launch = t_phase[1] / 2.0
         achieved = bytes_launch / t_launch / 1e9 if t_launch > 0 else None
         # HBM traffic of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
@@ -248,24 +270,30 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Preconditioner ApplyInverse DoF/s + achieved HBM GB/s, Stokes3D",
+            "metric": "Preconditioner ApplyInverse DoF/s + achieved HBM GB/s, %s" % {"stokes": "Stokes3D", "darcy": "Darcy3D", "cavity": "cavity3D Re=%g" % args.re}[args.problem],
             "value": N_global * args.steps / elapsed, "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong" if sharded or world == 1 else "weak", "vs_baseline": None, "dtype": "f64",
             "data": ("synthetic (HOST SIMULATOR, TEST ONLY - not a measurement)" if args.hostsim else
                      "synthetic (REHEARSAL: all ranks share one GPU - not a multi-GPU measurement)" if args.share_gpu else "synthetic"),
-            "config": {"workload": "GaleriExt Stokes3D %dx%dx%d (a=nx^2,b=1), %d DoF, HYMLS %d-level "
+            "config": {"workload": "%s %dx%dx%d, %d DoF, HYMLS %d-level "
                                    "(Number of Levels=%d), Skew Cartesian sx=%d, Block Diagonal, 1 rhs"
-                                   % (nx, ny, nz, N_global if sharded else N_local, levels + 1, levels, sx),
+                                   % ({"stokes": "GaleriExt Stokes3D (a=nx^2,b=1)", "darcy": "GaleriExt Darcy3D (a=1,b=-1)",
+                                       "cavity": "Navier-Stokes-like Jacobian Re=%g (Stokes3D + central convection, synthesised)" % args.re}[args.problem],
+                                      nx, ny, nz, N_global if sharded else N_local, levels + 1, levels, sx),
                        "parallelism": "1 GPU" if world == 1 else (
                            "sharded: %dx%dx%d boxes of %dx%dx%d cells, one per GPU; halo + V-sum exchange over torch.distributed (%s)"
                            % (px, py, pz, nx // px, ny // py, nz // pz, backend) if sharded else
                            (note or "%d replicas (one problem per GPU, no exchange)" % world)),
                        "levels": lv, "initialize_s": t_init, "compute_s": t_comp, "recompute_s": t_recomp,
                        "hbm_used_gib_rank0": hbm_used},
-            "hbm_gbps": bytes_all[0] / (elapsed / args.steps) / 1e9,
-            "apply_bytes": {"total": bytes_all[0], "interior_factors": bytes_all[1], "a12_a21": bytes_all[2],
-                            "separator_blocks_ot": bytes_all[3], "coarse": bytes_all[4], "vectors": bytes_all[5]},
+            "hbm_gbps": bytes_all[8] / (elapsed / args.steps) / 1e9,
+            "apply_bytes": {"total": bytes_all[8], "total_as_stored": bytes_all[0],
+                            "interior_factors_stored": bytes_all[1], "interior_factors_sparse_equivalent": bytes_all[6],
+                            "a12_a21": bytes_all[2], "separator_blocks_ot": bytes_all[3],
+                            "coarse_stored": bytes_all[4], "coarse_sparse_equivalent": bytes_all[7], "vectors": bytes_all[5],
+                            "note": "total = the smaller of stored (8 B x dense supernodal panel entries) and sparse-equivalent "
+                                    "(12 B x nnz(L+U) + 24 B per unknown) for every factor"},
             "phase_ms": {"apply": 1e3 * t_phase[0], "interior_solves(2 launches)": 1e3 * t_phase[1], "spmv": 1e3 * t_phase[2],
                          "schur": 1e3 * t_phase[3], "coarse": 1e3 * t_phase[4]},
             "roofline": {"kernel": "k_interior_fused", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

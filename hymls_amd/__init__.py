@@ -8,9 +8,16 @@ code + hand-written HIP kernels for gfx950).  There is no CPU fallback: if the
 HIP library is missing, importing :class:`Preconditioner` users get a loud error.
 """
 from .api import (Preconditioner, HymlsError, load_library, generate_matrix, generate_testvector, generate_rows,
-                  generate_testvector_rows, LIB_PATH)
+                  generate_testvector_rows, generate_problem, LIB_PATH)
 
-from .solver import Solver, BorderedSolver
+
+
+def __getattr__(name):
+    # the Krylov caller needs torch; the preconditioner itself does not (tools/pmc_driver.py runs without it)
+    if name in ("Solver", "BorderedSolver"):
+        from . import solver
+        return getattr(solver, name)
+    raise AttributeError("module 'hymls_amd' has no attribute %r" % name)
 
 __all__ = ["Solver", "BorderedSolver", "Preconditioner", "HymlsError", "load_library", "generate_matrix", "generate_testvector", "generate_rows",
-           "generate_testvector_rows", "LIB_PATH"]
+           "generate_testvector_rows", "generate_problem", "LIB_PATH"]

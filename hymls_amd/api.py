@@ -98,6 +98,8 @@ def load_library(path=None):
         "hymls_mi_get_separator_groups": (C.c_int, [H, C.c_int, C.c_int, _I32P, _I32P, _I32P, _I32P, _I32P]),
         "hymls_mi_generate_matrix": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                                C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I32P, _I32P, _F64P]),
+        "hymls_mi_generate_problem": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64,
+                                                _I32P, _I64P, _I32P, _I32P, _F64P]),
         "hymls_mi_generate_testvector": (C.c_int, [C.c_int64, _I32P, _I32P, _F64P, _F64P]),
         "hymls_mi_last_error": (C.c_char_p, [H]),
         "hymls_mi_destroy": (None, [H]),
@@ -154,6 +156,35 @@ def generate_rows(equations, nx, ny, nz, gids, a=None, b=1.0, lib=None):
     col = np.empty(max(nnz.value, 1), np.int32)
     val = np.empty(max(nnz.value, 1), np.float64)
     lib.hymls_mi_generate_rows(eq, nx, ny, nz, a, b, gids.size, _i32(gids), C.byref(nnz), _i32(rowptr), _i32(col), _f64(val))
+    return rowptr, col[:nnz.value], val[:nnz.value]
+
+
+_PROBLEM = {"Laplace": 0, "Stokes-C": 1, "Stokes": 1, "Darcy": 2, "Oseen": 3, "Cavity": 3}
+
+
+def generate_problem(problem, nx, ny, nz, a=None, b=None, re=0.0, gids=None, lib=None):
+    """CSR arrays (rowptr, global colind, val) of a BASELINE input (include/hymls_mi.h: hymls_mi_generate_problem):
+    'Laplace', 'Stokes' (a = nx^2, b = 1), 'Darcy' (a = 1, b = -1, reference src/HYMLS_MainUtils.cpp:300-306),
+    'Cavity' (Stokes + convection at Reynolds number `re`).  gids: only these rows (sharded runs)."""
+    lib = lib or load_library()
+    kind = _PROBLEM[problem]
+    if a is None:
+        a = 1.0 if kind == 2 else float(nx * nx)
+    if b is None:
+        b = -1.0 if kind == 2 else 1.0
+    n = nx * ny * nz * (1 if kind == 0 else 4)
+    gp = None
+    if gids is not None:
+        gids = np.ascontiguousarray(gids, dtype=np.int32)
+        n, gp = gids.size, _i32(gids)
+    nnz = C.c_int64()
+    ierr = lib.hymls_mi_generate_problem(kind, nx, ny, nz, a, b, re, n, gp, C.byref(nnz), None, None, None)
+    if ierr:
+        raise HymlsError(ierr, "generate_problem")
+    rowptr = np.empty(n + 1, np.int32)
+    col = np.empty(max(nnz.value, 1), np.int32)
+    val = np.empty(max(nnz.value, 1), np.float64)
+    lib.hymls_mi_generate_problem(kind, nx, ny, nz, a, b, re, n, gp, C.byref(nnz), _i32(rowptr), _i32(col), _f64(val))
     return rowptr, col[:nnz.value], val[:nnz.value]
 
 

@@ -8,7 +8,7 @@ namespace hymls {
 int64_t generate_laplace3d(int nx, int ny, int nz, int32_t* rowptr, int32_t* col, double* val);
 int64_t generate_stokes3d(int nx, int ny, int nz, double a, double b, int32_t* rowptr, int32_t* col, double* val);
 int64_t generate_rows(int equations, int nx, int ny, int nz, double a, double b, int64_t nrows, const int32_t* gids,
-                      int32_t* rowptr, int32_t* col, double* val);
+                      int32_t* rowptr, int32_t* col, double* val, double re);
 }
 
 using namespace hymls;
@@ -381,6 +381,10 @@ double hymls_mi_apply_bytes(const hymls_mi_t* h, int which) {
     case 3: return st.bytes_sep;
     case 4: return st.bytes_coarse;
     case 5: return st.bytes_vec;
+    case 6: return st.bytes_factor_sparse;
+    case 7: return st.bytes_coarse_sparse;
+    case 8: return std::min(st.bytes_factor, st.bytes_factor_sparse) + st.bytes_spmv + st.bytes_sep +
+                   std::min(st.bytes_coarse, st.bytes_coarse_sparse) + st.bytes_vec;
     default: return st.bytes_factor + st.bytes_spmv + st.bytes_sep + st.bytes_coarse + st.bytes_vec;
   }
 }
@@ -453,7 +457,18 @@ int hymls_mi_generate_matrix(int equations, int nx, int ny, int nz, double a, do
 int hymls_mi_generate_rows(int equations, int nx, int ny, int nz, double a, double b, int64_t nrows, const int32_t* gids,
                            int64_t* nnz, int32_t* rowptr, int32_t* colgid, double* val) {
   if (!nnz || !gids || (equations != 0 && equations != 1)) return -2;
-  try { *nnz = generate_rows(equations, nx, ny, nz, a, b, nrows, gids, rowptr, colgid, val); }
+  try { *nnz = generate_rows(equations, nx, ny, nz, a, b, nrows, gids, rowptr, colgid, val, 0.0); }
+  catch (...) { return -2; }
+  return 0;
+}
+
+int hymls_mi_generate_problem(int problem, int nx, int ny, int nz, double a, double b, double re, int64_t nrows,
+                              const int32_t* gids, int64_t* nnz, int32_t* rowptr, int32_t* colgid, double* val) {
+  if (!nnz || problem < 0 || problem > 3 || nx <= 0 || ny <= 0 || nz <= 0) return -2;
+  const int64_t N = (int64_t)nx * ny * nz * (problem == 0 ? 1 : 4);
+  if (!gids && nrows != N) return -2;
+  if (gids) for (int64_t t = 0; t < nrows; t++) if (gids[t] < 0 || gids[t] >= N) return -2;
+  try { *nnz = generate_rows(problem, nx, ny, nz, a, b, nrows, gids, rowptr, colgid, val, re); }
   catch (...) { return -2; }
   return 0;
 }

@@ -195,17 +195,21 @@ template <int L>
 __global__ void k_spmv(int32_t nrows, const int32_t* __restrict__ rp, const int32_t* __restrict__ col,
                        const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
                        double alpha, double beta) {
-  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t row = gt / L;
-  const int lane = (int)(gt % L);
-  double s = 0.0;
-  if (row < nrows) {
-    const int b = rp[row], e = rp[row + 1];
-    for (int k = b + lane; k < e; k += L) s += val[k] * x[col[k]];
-  }
+  const int lane = (int)(threadIdx.x % L);
+  const int rpb = (int)blockDim.x / L;   // rows per block and pass
+  // grid-stride over blocks of rows: the trip count is uniform inside a workgroup, so every lane of a sub-wave takes
+  // part in the shuffles (the grid is capped at 2^20 workgroups)
+  for (int64_t base = (int64_t)blockIdx.x * rpb; base < nrows; base += (int64_t)gridDim.x * rpb) {
+    const int64_t row = base + threadIdx.x / L;
+    double s = 0.0;
+    if (row < nrows) {
+      const int b = rp[row], e = rp[row + 1];
+      for (int k = b + lane; k < e; k += L) s += val[k] * x[col[k]];
+    }
 #pragma unroll
-  for (int off = L / 2; off > 0; off >>= 1) s += __shfl_down(s, off, L);
-  if (row < nrows && lane == 0) y[row] = alpha * s + (beta == 0.0 ? 0.0 : beta * y[row]);
+    for (int off = L / 2; off > 0; off >>= 1) s += __shfl_down(s, off, L);
+    if (row < nrows && lane == 0) y[row] = alpha * s + (beta == 0.0 ? 0.0 : beta * y[row]);
+  }
 }
 void spmv(int32_t nrows, const int32_t* rp, const int32_t* col, const double* val, const double* x, double* y,
           double alpha, double beta, int64_t nnz_hint) {

@@ -61,18 +61,74 @@ inline void stokes_row(int nx, int ny, int nz, double a, double b, int32_t r, Ro
   }
   std::sort(row.begin(), row.end());
 }
+
+// GaleriExt::Darcy3D (reference src/GaleriExt_Darcy3D.h:45-176; create_matrix passes a = 1, b = -1,
+// src/HYMLS_MainUtils.cpp:300-306): diag(a) on the velocities, -b / +b on this and the next cell's pressure,
+// divergence rows with c = -b and no diagonal entry.
+inline void darcy_row(int nx, int ny, int nz, double a, double b, int32_t r, Row& row) {
+  row.clear();
+  const int dof = 4;
+  const int var = r % dof, c = r / dof;
+  const int ijk[3] = {c % nx, (c / nx) % ny, c / (nx * ny)};
+  const int n[3] = {nx, ny, nz};
+  const int step[3] = {1, nx, nx * ny};
+  if (var < 3) {
+    row.emplace_back(r, a);
+    if (ijk[var] < n[var] - 1) {
+      row.emplace_back(c * dof + 3, -b);
+      row.emplace_back((c + step[var]) * dof + 3, b);
+    }
+  } else {
+    const double cc = -b;
+    for (int d = 0; d < 3; d++) {
+      if (ijk[d] < n[d] - 1) row.emplace_back(c * dof + d, -cc);
+      if (ijk[d] > 0) row.emplace_back((c - step[d]) * dof + d, cc);
+    }
+  }
+  std::sort(row.begin(), row.end());
+}
+
+// BASELINE configs[3]: a Navier-Stokes-like (Oseen) Jacobian.  The reference ships no 3D Jacobian at Re > 0
+// (testSuite/cavity3D.xml reads a file that is a missing blob), so the matrix is synthesised:
+// Stokes3D(a, b) plus the central difference of (w . grad) u on every existing velocity-velocity coupling, scaled
+// like the diffusion (the Stokes rows are multiplied by Re): +-g w_d towards the next / previous neighbour in
+// direction d with g = a Re / (2 nx), i.e. a cell Peclet number of Re |w| h / 2.  w is a fixed swirling field,
+// w = (-y + 0.3 z, x - 0.2 z, 0.5 x y) at the cell centre, x = (i + 1/2) / nx - 1/2 etc.  Gradient and divergence
+// entries are untouched (the matrix stays an F-matrix), the pattern is that of Stokes3D.
+inline void oseen_row(int nx, int ny, int nz, double a, double b, double re, int32_t r, Row& row) {
+  stokes_row(nx, ny, nz, a, b, r, row);
+  const int dof = 4;
+  const int var = r % dof, c = r / dof;
+  if (var == 3 || row.size() == 1) return;
+  const int i = c % nx, j = (c / nx) % ny, k = c / (nx * ny);
+  const double x = (i + 0.5) / nx - 0.5, y = (j + 0.5) / ny - 0.5, z = (k + 0.5) / nz - 0.5;
+  const double w[3] = {-y + 0.3 * z, x - 0.2 * z, (0.5 * x) * y};
+  const double g = re / (2.0 * nx) * a;
+  const int step[3] = {1, nx, nx * ny};
+  for (auto& e : row) {
+    if (e.first % dof != var || e.first == r) continue;
+    const int diff = e.first / dof - c;
+    for (int d = 0; d < 3; d++) {
+      if (diff == step[d]) e.second += g * w[d];
+      else if (diff == -step[d]) e.second += (-g) * w[d];
+    }
+  }
+}
 }  // namespace
 
-// rows `gids` (nullptr: all rows 0..nrows-1) of the matrix; returns nnz; if rowptr != nullptr also fills
+// rows `gids` (nullptr: all rows 0..nrows-1) of the matrix (equations: 0 Laplace, 1 Stokes3D, 2 Darcy3D,
+// 3 Stokes3D + convection at Reynolds number re); returns nnz; if rowptr != nullptr also fills
 // the arrays (sorted global columns per row)
 int64_t generate_rows(int equations, int nx, int ny, int nz, double a, double b, int64_t nrows, const int32_t* gids,
-                      int32_t* rowptr, int32_t* col, double* val) {
+                      int32_t* rowptr, int32_t* col, double* val, double re) {
   Row row;
   int64_t nnz = 0;
   for (int64_t t = 0; t < nrows; t++) {
     const int32_t r = gids ? gids[t] : (int32_t)t;
     if (equations == 0) laplace_row(nx, ny, nz, r, row);
-    else stokes_row(nx, ny, nz, a, b, r, row);
+    else if (equations == 1) stokes_row(nx, ny, nz, a, b, r, row);
+    else if (equations == 2) darcy_row(nx, ny, nz, a, b, r, row);
+    else oseen_row(nx, ny, nz, a, b, re, r, row);
     if (rowptr) {
       rowptr[t] = (int32_t)nnz;
       for (auto& e : row) { col[nnz] = e.first; val[nnz] = e.second; nnz++; }
@@ -86,11 +142,11 @@ int64_t generate_rows(int equations, int nx, int ny, int nz, double a, double b,
 }
 
 int64_t generate_laplace3d(int nx, int ny, int nz, int32_t* rowptr, int32_t* col, double* val) {
-  return generate_rows(0, nx, ny, nz, 0, 0, (int64_t)nx * ny * nz, nullptr, rowptr, col, val);
+  return generate_rows(0, nx, ny, nz, 0, 0, (int64_t)nx * ny * nz, nullptr, rowptr, col, val, 0.0);
 }
 
 int64_t generate_stokes3d(int nx, int ny, int nz, double a, double b, int32_t* rowptr, int32_t* col, double* val) {
-  return generate_rows(1, nx, ny, nz, a, b, (int64_t)nx * ny * nz * 4, nullptr, rowptr, col, val);
+  return generate_rows(1, nx, ny, nz, a, b, (int64_t)nx * ny * nz * 4, nullptr, rowptr, col, val, 0.0);
 }
 
 }  // namespace hymls

@@ -387,6 +387,7 @@ void DirectSolver::apply_inverse_bordered(const double* b, const double* T, doub
 void DirectSolver::add_stats(ApplyStats& st, bool) const {
   if (!lu_) return;
   st.bytes_coarse += 8.0 * lu_->plan.nnz_factor + 8.0 * 4 * n_;
+  st.bytes_coarse_sparse += 12.0 * lu_->plan.nnz_sparse + 24.0 * n_ + 8.0 * 4 * n_;
 }
 
 // ------------------------------------------------------------------ LevelSolver
@@ -1860,8 +1861,11 @@ void LevelSolver::matvec(const double* x, double* y) {
 }
 
 void LevelSolver::add_stats(ApplyStats& st, bool as_coarse) const {
-  double f = 0, sp = 0, sep = 0, vec = 0;
-  for (auto& cp : cls_) f += 2.0 * 8.0 * (double)cp->lu.plan.nnz_factor * (double)cp->lu.members.size();
+  double f = 0, fs = 0, sp = 0, sep = 0, vec = 0;
+  for (auto& cp : cls_) {
+    f += 2.0 * 8.0 * (double)cp->lu.plan.nnz_factor * (double)cp->lu.members.size();
+    fs += 2.0 * (12.0 * (double)cp->lu.plan.nnz_sparse + 24.0 * cp->lu.plan.nI) * (double)cp->lu.members.size();
+  }
   sp = 12.0 * (double)(a12_col_.size() + a21_col_.size()) + 4.0 * (n1_ + n2_ + 2);
   if (!direct_schur_) {
     sep = 2.0 * 12.0 * n2_;
@@ -1869,8 +1873,8 @@ void LevelSolver::add_stats(ApplyStats& st, bool as_coarse) const {
   }
   const double N = (double)(n1_ + n2_);
   vec = 8.0 * (4.0 * N + 7.0 * n1_ + 12.0 * n2_);
-  if (as_coarse) st.bytes_coarse += f + sp + sep + vec;
-  else { st.bytes_factor += f; st.bytes_spmv += sp; st.bytes_sep += sep; st.bytes_vec += vec; }
+  if (as_coarse) { st.bytes_coarse += f + sp + sep + vec; st.bytes_coarse_sparse += fs + sp + sep + vec; }
+  else { st.bytes_factor += f; st.bytes_factor_sparse += fs; st.bytes_spmv += sp; st.bytes_sep += sep; st.bytes_vec += vec; }
   if (next_) next_->add_stats(st, true);
 }
 

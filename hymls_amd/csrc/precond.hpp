@@ -17,6 +17,9 @@ namespace hymls {
 
 struct ApplyStats {
   double bytes_factor = 0, bytes_spmv = 0, bytes_sep = 0, bytes_coarse = 0, bytes_vec = 0;
+  // the same with every factor counted as a sparse solver would stream it: nnz(L + U) x (8 B value + 4 B index) +
+  // 24 B of permutation / scaling data per unknown (reference KluSolve, src/HYMLS_SparseDirectSolver.cpp:788-856)
+  double bytes_factor_sparse = 0, bytes_coarse_sparse = 0;
 };
 
 // batched multifrontal LU of one pattern class, resident on the device

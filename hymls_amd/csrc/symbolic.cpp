@@ -1,5 +1,6 @@
 // symbolic.cpp -- see symbolic.hpp
 #include "symbolic.hpp"
+#include <iterator>
 
 namespace hymls {
 
@@ -301,6 +302,31 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   HYMLS_CHECK((int)P.perm.size() == nI, -3, "ordering lost nodes");
   P.iperm.assign(nI, -1);
   for (int i = 0; i < nI; i++) P.iperm[P.perm[i]] = i;
+  // --- sparse-equivalent size of the factors: nnz(L + U) of a scalar (column by column) LU of the interior block in this
+  //     elimination order, without supernode padding, dense leaves or explicit triangular inverses -- what a sparse
+  //     solver such as the reference's KLU would stream per solve (the smaller of this and the stored
+  //     footprint is the algorithmic figure).  Column structures are merged up the elimination tree.
+  {
+    std::vector<ivec> st(nI);        // struct(L_j) as elimination positions > j (interior only)
+    std::vector<ivec> ekids(nI);
+    int64_t nnz = 0;
+    ivec tmp;
+    for (int j = 0; j < nI; j++) {
+      ivec& S = st[j];
+      for (int u : adj[P.perm[j]]) if (u < nI && P.iperm[u] > j) S.push_back(P.iperm[u]);
+      std::sort(S.begin(), S.end());
+      for (int ch : ekids[j]) {
+        tmp.clear();
+        const ivec& C = st[ch];
+        std::set_union(S.begin(), S.end(), std::upper_bound(C.begin(), C.end(), j), C.end(), std::back_inserter(tmp));
+        S.swap(tmp);
+        ivec().swap(st[ch]);
+      }
+      nnz += 1 + 2 * (int64_t)S.size();
+      if (!S.empty()) ekids[S[0]].push_back(j);
+    }
+    P.nnz_sparse = nnz;
+  }
   // wide supernodes stay whole (their pivot block is factored piece by piece in place and then
   // inverted explicitly, so that the solve needs one panel product per supernode)
   const int nf = (int)sn.size();

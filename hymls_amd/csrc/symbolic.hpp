@@ -80,7 +80,8 @@ struct ClassPlan {
   int32_t contrib_size = 0;   // doubles of solve scratch per subdomain
   int32_t max_front = 0;      // max m
   int32_t max_solve_rows = 0; // max w + ri
-  int64_t nnz_factor = 0;     // stored panel entries (= algorithmic factor footprint)
+  int64_t nnz_factor = 0;     // stored panel entries (dense supernodal panels incl. explicit triangular inverses)
+  int64_t nnz_sparse = 0;     // nnz(L + U) of the scalar LU in the same order (sparse-equivalent footprint)
   int64_t flops_factor = 0;
 };
 

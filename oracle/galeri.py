@@ -143,6 +143,38 @@ def stokes3d(nx, ny, nz, a=None, b=1.0):
     return A
 
 
+def oseen3d(nx, ny, nz, re, a=None, b=1.0):
+    """BASELINE configs[3]: the reference ships no 3D Navier-Stokes Jacobian at Re > 0
+    (testSuite/cavity3D.xml reads data/DrivenCavity/32x32x32/Re0/jac.mtx, a missing blob), so the input is
+    synthesised: Stokes3D(a, b) (velocity rows scaled like the reference's, i.e. multiplied by Re) plus the
+    central difference of (w . grad) u on every existing velocity-velocity coupling: +g w_d to the next,
+    -g w_d to the previous neighbour in direction d, g = a Re / (2 nx) (cell Peclet number Re |w| h / 2),
+    w = (-y + 0.3 z, x - 0.2 z, 0.5 x y) at the cell centre, x = (i + 1/2)/nx - 1/2 etc.  Gradient and
+    divergence entries are untouched (F-matrix), the pattern is that of Stokes3D.  Parity unpinned by the
+    reference (no fixture exists); the product generator is pinned to this one bit for bit."""
+    if a is None:
+        a = float(nx * nx)
+    A = stokes3d(nx, ny, nz, a, b).tocsr()
+    A.sort_indices()
+    rows = np.repeat(np.arange(A.shape[0]), np.diff(A.indptr))
+    cols = A.indices
+    var_r, var_c = rows % 4, cols % 4
+    cell_r, cell_c = rows // 4, cols // 4
+    diff = cell_c - cell_r
+    i, j, k = cell_r % nx, (cell_r // nx) % ny, cell_r // (nx * ny)
+    x, y, z = (i + 0.5) / nx - 0.5, (j + 0.5) / ny - 0.5, (k + 0.5) / nz - 0.5
+    w = [-y + 0.3 * z, x - 0.2 * z, (0.5 * x) * y]
+    g = re / (2.0 * nx) * a
+    nent = np.diff(A.indptr)[rows]
+    data = A.data.copy()
+    for d, st in enumerate((1, nx, nx * ny)):
+        for sgn in (+1, -1):
+            m = (var_r < 3) & (var_r == var_c) & (diff == sgn * st) & (nent > 1)
+            data[m] += (sgn * g) * w[d][m]
+    A.data = data
+    return A
+
+
 def create_testvector(A):
     """create_testvector (src/HYMLS_MainUtils.cpp:208-258), Stokes-C / Laplace:
     all ones, zero on rows whose only nonzero is the diagonal."""

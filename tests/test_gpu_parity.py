@@ -236,20 +236,19 @@ def test_darcy3d_saddle_point_gpu(gpu_lib):
     assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-8
 
 
-@pytest.mark.gpu
-def test_full_size_properties_128(gpu_lib):
-    """Size-independent properties at a BASELINE size the oracle cannot reach (Stokes3D 128^3, 3-level, Skew,
-    sx=8; 8.4 M DoF): the operator is linear, reproducible bit for bit, maps pressure-free right-hand sides to
-    divergence-free velocities (reference integration_tests.cpp:453-484, 1e-8), and is a contraction-grade
-    preconditioner (one Richardson step reduces the residual)."""
+def full_size_properties(gpu_lib, problem, n, levels, re=0.0, max_its=400, sizes=None):
+    """Size-independent properties at a BASELINE size the oracle cannot reach: the operator is linear, reproducible
+    bit for bit, maps pressure-free right-hand sides to divergence-free velocities (reference
+    integration_tests.cpp:453-484, 1e-8), and right-preconditioned GMRES on the device (BaseSolver semantics,
+    reference src/HYMLS_BaseSolver.cpp:309-397: zero initial guess, b = K x_ex) reaches a relative residual of 1e-8."""
     import torch
     import hymls_amd
-    n = 128
-    rp, ci, va = hymls_amd.generate_matrix("Stokes-C", n, n, n, lib=gpu_lib)
+    rp, ci, va = hymls_amd.generate_problem(problem, n, n, n, re=re, lib=gpu_lib)
     tv = hymls_amd.generate_testvector(rp, ci, va, lib=gpu_lib)
-    P = hymls_amd.Preconditioner((rp, ci, va), xml_params("Stokes-C", n, 8, 2, partitioner="Skew Cartesian"), testVector=tv, lib=gpu_lib)
+    P = hymls_amd.Preconditioner((rp, ci, va), xml_params("Stokes-C", n, 8, levels, partitioner="Skew Cartesian"), testVector=tv, lib=gpu_lib)
     P.Compute()
-    assert [s[1] for s in P.level_sizes()] == [8388608, 216096, 468]
+    if sizes:
+        assert [s[1] for s in P.level_sizes()] == sizes
     N = rp.size - 1
     g = torch.Generator(device="cuda"); g.manual_seed(7)
     b1 = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
@@ -265,16 +264,36 @@ def test_full_size_properties_128(gpu_lib):
     torch.cuda.synchronize()
     assert float(y[3::4].abs().max()) <= 1e-8 * N                                        # divergence-free velocities
     # (not a contraction: ||b - K P b|| >> ||b|| for right-hand sides with a divergence part also with the oracle)
-    # right-preconditioned GMRES on the device (BaseSolver semantics, reference src/HYMLS_BaseSolver.cpp:309-397):
-    # zero initial guess, b = K x_ex, relative residual 1e-8
     x_ex = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
     rhs = P.MatVec(x_ex).clone()
-    S = hymls_amd.Solver(P, P, {"Krylov Method": "GMRES", "Iterative Solver": {"Convergence Tolerance": 1e-8, "Maximum Iterations": 400, "Num Blocks": 400}})
+    S = hymls_amd.Solver(P, P, {"Krylov Method": "GMRES", "Iterative Solver": {"Convergence Tolerance": 1e-8, "Maximum Iterations": max_its, "Num Blocks": max_its}})
     xs = S.ApplyInverse(rhs)
     its = S.getNumIter()
     true_rel = float((rhs - P.MatVec(xs)).norm() / rhs.norm())
-    print("GMRES(128^3, 3-level): %d iterations, true relative residual %.2e" % (its, true_rel))
-    assert its < 400 and true_rel < 1e-7
+    print("GMRES(%s %d^3 re=%g, Number of Levels=%d): %d iterations, true relative residual %.2e" % (problem, n, re, levels, its, true_rel))
+    assert its < max_its and true_rel < 1e-7
+    return its
+
+
+@pytest.mark.gpu
+def test_full_size_properties_128(gpu_lib):
+    """BASELINE configs[1]/[2] family: Stokes3D 128^3, 3-level, Skew, sx = 8 (8.4 M DoF)"""
+    full_size_properties(gpu_lib, "Stokes", 128, 2, sizes=[8388608, 216096, 468])
+
+
+@pytest.mark.gpu
+def test_full_size_cavity_re1000_128(gpu_lib):
+    """BASELINE configs[3] at its size: Navier-Stokes-like Jacobian at Re = 1000 on 128^3 (cell Peclet numbers up to 2.5:
+    the velocity blocks are not diagonally dominant), one MI355X, 2-level and 3-level."""
+    full_size_properties(gpu_lib, "Cavity", 128, 1, re=1000.0, max_its=500, sizes=[8388608, 216096])
+    full_size_properties(gpu_lib, "Cavity", 128, 2, re=1000.0, max_its=500, sizes=[8388608, 216096, 468])
+
+
+@pytest.mark.gpu
+def test_full_size_darcy_128(gpu_lib):
+    """BASELINE configs[4] (GaleriExt Darcy3D, a = 1, b = -1) at the largest size one quarter of the 4-GPU run holds
+    comfortably inside a test: 128^3 on one MI355X (bench.py --problem darcy --grid 256 runs the 256^3 problem)."""
+    full_size_properties(gpu_lib, "Darcy", 128, 2, sizes=[8388608, 216096, 468])
 
 
 @pytest.mark.gpu
@@ -296,6 +315,34 @@ def test_reference_driven_cavity_2d_gpu(gpu_lib, re, part, levels, its_max):
     """the reference's 2D driven-cavity Jacobian at Re 1000 (its own test data) on the GPU path"""
     from test_hostsim_parity import cavity2d_case
     cavity2d_case(gpu_lib, re, part, levels, its_max)
+
+
+@pytest.mark.gpu
+def test_reference_driven_cavity_2d_64_gpu(gpu_lib):
+    """the reference's 64x64 Re 1000 system (the reference-pinned robustness check), 3-level, GPU path:
+    oracle parity of one ApplyInverse, same GMRES iteration count, the stored solution is reached"""
+    from test_hostsim_parity import cavity2d_case
+    cavity2d_case(gpu_lib, "re1000", "Cartesian", 2, 250, grid=64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels,tol,re", [(1, 1e-8, 10000.0), (1, 1e-8, 500.0)])
+def test_high_reynolds_robustness_gpu(gpu_lib, levels, tol, re):
+    """pivot-free interior factorisation where the velocity rows have lost diagonal dominance: the add_convection
+    case re = 10000 on 16^3 (cell Reynolds number 625) and the configs[3] generator at a cell Peclet number four
+    times that of Re = 1000 on 128^3, GPU path against the oracle (SuperLU with partial pivoting)"""
+    from common import add_convection
+    from oracle import galeri
+    n = 16
+    if re > 1000:
+        A, tv = problem("Stokes-C", n)
+        A = add_convection(A, n, re=re)
+    else:
+        A = galeri.oseen3d(n, n, n, re); tv = galeri.create_testvector(A)
+    P = product_prec(A, tv, xml_params("Stokes-C", n, 8, levels, partitioner="Skew Cartesian"), gpu_lib)
+    O = oracle_prec(A, tv, "Stokes-C", n, 8, levels, partitioner="Skew Cartesian")
+    b = np.random.default_rng(21).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < tol
 
 
 @pytest.mark.gpu

@@ -50,6 +50,42 @@ def test_cpp_generator_matches_oracle_generator(hostsim_lib):
         assert abs(sp.csr_matrix((va, ci, rp)) - galeri.laplace3d(n, n, n)).max() == 0
 
 
+@pytest.mark.parametrize("dims", [(8, 8, 8), (12, 12, 12), (6, 8, 10)])
+def test_cpp_darcy_and_oseen_generators_match_oracle_bit_for_bit(dims):
+    """BASELINE configs[3]/[4] inputs: the product's row-wise generators (hymls_mi_generate_problem, called through the
+    product library: no GPU needed) against oracle/galeri.py, entry for entry, whole matrix and a list of rows."""
+    import hymls_amd
+    nx, ny, nz = dims
+    for name, A in (("Darcy", galeri.darcy3d(nx, ny, nz, 1.0, -1.0)), ("Cavity", galeri.oseen3d(nx, ny, nz, 300.0)),
+                    ("Stokes", galeri.stokes3d(nx, ny, nz)), ("Laplace", galeri.laplace3d(nx, ny, nz))):
+        A = A.tocsr(); A.sort_indices()
+        rp, ci, va = hymls_amd.generate_problem(name, nx, ny, nz, re=300.0)
+        assert np.array_equal(rp, A.indptr) and np.array_equal(ci, A.indices), name
+        assert np.array_equal(va, A.data), name
+        rows = np.random.default_rng(5).choice(A.shape[0], 57, replace=False).astype(np.int32)
+        rp2, ci2, va2 = hymls_amd.generate_problem(name, nx, ny, nz, re=300.0, gids=rows)
+        B = A[rows]
+        assert np.array_equal(rp2, B.indptr) and np.array_equal(ci2, B.indices) and np.array_equal(va2, B.data), name
+
+
+def test_darcy3d_reference_unit_test_properties():
+    """reference testSuite/unit_tests/GaleriExt_Darcy3D.cpp:13-267: diagonal a on velocity rows / none on pressure rows,
+    B part structurally anti-symmetric ([A B'; -B 0] with c = -b), gradient rows sum to zero."""
+    n, a, b = 6, 2.5, -1.0
+    A = galeri.darcy3d(n, n, n, a, b).tocsr()
+    d = A.diagonal()
+    assert np.all(d[np.arange(A.shape[0]) % 4 != 3] == a) and np.all(d[3::4] == 0)
+    vel = np.arange(A.shape[0]) % 4 != 3
+    G = A[vel][:, ~vel]; D = A[~vel][:, vel]
+    assert abs(G + D.T).max() == 0
+    assert abs(np.asarray(G.sum(axis=1))).max() == 0
+    # the Oseen matrix keeps the Stokes pattern and its gradient / divergence entries
+    S = galeri.stokes3d(n, n, n).tocsr(); O = galeri.oseen3d(n, n, n, 500.0).tocsr()
+    assert np.array_equal(S.indptr, O.indptr) and np.array_equal(S.indices, O.indices)
+    assert abs(S[vel][:, ~vel] - O[vel][:, ~vel]).max() == 0 and abs(S[~vel] - O[~vel]).max() == 0
+    assert abs(O - O.T).max() > 1.0
+
+
 def _is_group(gsd, nsx, nsy, nsz):
     g = [1] * 27
     if (gsd + 1) % nsx == 0:
@@ -206,3 +242,48 @@ def test_oracle_bordered_apply_inverse_is_exact_on_one_level(with_c):
     s_ex = rng.uniform(-1, 1, m) if with_c else np.zeros(m)
     x, s = P.apply_inverse_bordered(A @ x_ex + V @ s_ex, W.T @ x_ex + C @ s_ex)
     assert np.abs(x - x_ex).max() < 1e-10 and np.abs(s - s_ex).max() < 1e-10
+
+
+def test_cartesian_partitioner_gives_zero_pressure_blocks_for_3d_stokes():
+    """The deviation from BASELINE's north_star, pinned: with the *Cartesian* partitioner a 3D Stokes-C problem has
+    pressure-only separator groups (the pressure "tubes" on subdomain edges, reference
+    src/HYMLS_CartesianPartitioner.cpp:326-339) that couple only to separator velocities of other groups.  After the
+    orthogonal transformation and the dropping of everything outside a group's own block
+    (src/HYMLS_SchurPreconditioner.cpp:877-986) their diagonal blocks are EXACTLY zero, so the dgetrf of
+    SchurPreconditioner.cpp:284-291 returns INFO > 0 and the block solve of :1311-1346 divides by zero.  This is why
+    every 3D Stokes integration test of the reference (stokes{0,1,2,4}_3D.xml) uses "Skew Cartesian", and why the
+    BASELINE 3D Stokes configurations are run with it here (the product returns -4 for the Cartesian case:
+    tests/test_hostsim_parity.py::test_lifecycle_and_errors)."""
+    import warnings
+    n, sx = 8, 4
+    A = galeri.stokes3d(n, n, n)
+    tv = galeri.create_testvector(A)
+    p = Params(nx=n, ny=n, nz=n, sx=sx, levels=1, equations="Stokes-C").finalize()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        O = Preconditioner(A, p, testvector=tv).compute()
+    S, hm = O.schur, O.hm
+    npress, nzero, nother_singular = 0, 0, 0
+    for sd in range(hm.nsd):
+        for L in hm.owned_linked(sd):
+            ids = np.concatenate([O.pos2[hm.groups[sd][gi][1][1:]] for gi in L])
+            if ids.size == 0:
+                continue
+            D = S.matrix[ids][:, ids].toarray()
+            if np.all(O.map2[ids] % 4 == 3):
+                npress += 1
+                nzero += int(np.abs(D).max() == 0.0)
+            elif np.linalg.cond(D) > 1e14:
+                nother_singular += 1
+    assert npress > 0 and nzero == npress, "every pressure-only block is exactly zero"
+    assert nother_singular == 0, "all other blocks are regular"
+    x = O.apply_inverse(np.ones(A.shape[0]))
+    assert not np.isfinite(x).all()
+    # the same problem with the Skew Cartesian partitioner has no pressure-only block at all
+    ps = Params(nx=n, ny=n, nz=n, sx=sx, levels=1, equations="Stokes-C", partitioner="Skew Cartesian").finalize()
+    Os = Preconditioner(A, ps, testvector=tv).compute()
+    for sd in range(Os.hm.nsd):
+        for L in Os.hm.owned_linked(sd):
+            ids = np.concatenate([Os.pos2[Os.hm.groups[sd][gi][1][1:]] for gi in L])
+            assert ids.size == 0 or not np.all(Os.map2[ids] % 4 == 3)
+    assert np.isfinite(Os.apply_inverse(np.ones(A.shape[0]))).all()

@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
+                    help="sharded runs: 'rccl' = the library's built-in transport (ncclSend/ncclRecv groups on its stream, "
+                         "no Python inside ApplyInverse); 'torch' = callbacks into torch.distributed.all_to_all_single")
     ap.add_argument("--hostsim", action="store_true",
                     help="TEST ONLY: drive the host-logic simulator on the CPU (tests/test_bench_multirank.py); "
                          "numbers produced this way are meaningless and are marked as such")
@@ -141,8 +144,9 @@ def main():
     if sharded:
         # self-test of the transport on this backend (uneven all-to-all on the library's stream); a failure ends the
         # run with a non-zero exit code: N replicas under the sharded metric would inflate the number
-        from hymls_amd.dist import TorchComm, rank_grid, transport_selftest
-        err = transport_selftest(dev, backend)
+        from hymls_amd.dist import TorchComm, RcclComm, rank_grid, transport_selftest
+        native = args.transport == "rccl" and not args.hostsim and not args.share_gpu and backend == "nccl"
+        err = None if native else transport_selftest(dev, backend)   # (the built-in transport fails loudly by itself)
         if err:
             sys.stderr.write("bench.py: sharded transport self-test failed on rank %d (%s); no fallback\n" % (rank, err))
             dist.destroy_process_group()
@@ -153,7 +157,7 @@ def main():
         nx, ny, nz = n, n, n
         prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": nx, "ny": ny, "nz": nz},
                "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
-        comm = TorchComm(dev)
+        comm = RcclComm(local_rank, lib=lib) if native else TorchComm(dev)
         P = hymls_amd.Preconditioner(None, prm, device=local_rank, lib=lib, comm=comm, rank_grid=(px, py, pz))
         t0 = time.time()
         req = P.RequiredRows()
@@ -252,23 +256,20 @@ def main():
         t_launch = t_phase[1] / 2.0
         achieved = bytes_launch / t_launch / 1e9 if t_launch > 0 else None
         # HBM traffic of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
-        # gfx950 1/2-fetch correction calibrated in the same pass): committed measurement, used only when it was
-        # taken on this very workload; rocprofv3 --pmc crashes at 128^3, so the 112^3 measurement is attached as
-        # `traffic_measured_on` and `traffic` stays null for the default grid.
+        # gfx950 1/2-fetch correction checked in the same pass on k_axpby; tools/pmc_driver.py + tools/pmc_summary.py):
+        # committed measurement under profiles/, used only when it was taken on this very workload.
         traffic, traffic_other = None, None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_interior_fused.json")
-        if os.path.exists(prof):
+        import glob
+        for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_interior_fused.json")), reverse=True):
             try:
                 pj = json.load(open(prof))
-                if pj.get("n") == n and pj.get("sx") == sx and pj.get("levels") == levels:
+                if (pj.get("n") == n and pj.get("sx") == sx and pj.get("levels") == levels and args.problem == "stokes"
+                        and world == 1):
                     traffic = pj.get("hbm_bytes_per_launch")
-                else:
-                    traffic_other = {"workload": "Stokes3D %d^3, sx=%d, Number of Levels=%d" % (pj["n"], pj["sx"], pj["levels"]),
-                                     "hbm_bytes_per_launch": pj["hbm_bytes_per_launch"],
-                                     "algorithmic_bytes_per_launch": pj["algorithmic_bytes_per_launch"],
-                                     "traffic_over_algorithmic": pj["traffic_over_algorithmic"]}
+                    traffic_other = {"source": os.path.basename(prof), "traffic_over_algorithmic": pj.get("traffic_over_algorithmic")}
+                    break
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "Preconditioner ApplyInverse DoF/s + achieved HBM GB/s, %s" % {"stokes": "Stokes3D", "darcy": "Darcy3D", "cavity": "cavity3D Re=%g" % args.re}[args.problem],
             "value": N_global * args.steps / elapsed, "unit": "DoF/s",
@@ -282,8 +283,10 @@ def main():
                                        "cavity": "Navier-Stokes-like Jacobian Re=%g (Stokes3D + central convection, synthesised)" % args.re}[args.problem],
                                       nx, ny, nz, N_global if sharded else N_local, levels + 1, levels, sx),
                        "parallelism": "1 GPU" if world == 1 else (
-                           "sharded: %dx%dx%d boxes of %dx%dx%d cells, one per GPU; halo + V-sum exchange over torch.distributed (%s)"
-                           % (px, py, pz, nx // px, ny // py, nz // pz, backend) if sharded else
+                           "sharded: %dx%dx%d boxes of %dx%dx%d cells, one per GPU; halo + V-sum exchange over %s, RCCL ranks = %d"
+                           % (px, py, pz, nx // px, ny // py, nz // pz,
+                              "the built-in RCCL transport (ncclSend/ncclRecv groups on the library's stream)" if native
+                              else "torch.distributed (%s) callbacks" % backend, world) if sharded else
                            (note or "%d replicas (one problem per GPU, no exchange)" % world)),
                        "levels": lv, "initialize_s": t_init, "compute_s": t_comp, "recompute_s": t_recomp,
                        "hbm_used_gib_rank0": hbm_used},

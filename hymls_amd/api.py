@@ -65,6 +65,10 @@ def load_library(path=None):
         "hymls_mi_create": (C.c_int, [C.POINTER(H), C.POINTER(_Params), C.c_int]),
         "hymls_mi_set_matrix_csr": (C.c_int, [H, C.c_int64, _I32P, _I32P, _F64P]),
         "hymls_mi_set_comm": (C.c_int, [H, C.POINTER(_Comm), C.c_int, C.c_int, C.c_int]),
+        "hymls_mi_rccl_unique_id": (C.c_int, [C.c_char_p]),
+        "hymls_mi_rccl_comm_init": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+        "hymls_mi_rccl_comm_destroy": (None, [C.c_void_p]),
+        "hymls_mi_set_comm_rccl": (C.c_int, [H, C.c_void_p, C.c_int, C.c_int, C.c_int]),
         "hymls_mi_required_rows": (C.c_int, [H, _I64P, _I32P]),
         "hymls_mi_set_matrix_rows": (C.c_int, [H, C.c_int64, _I32P, _I32P, _I32P, _F64P]),
         "hymls_mi_owned_rows": (C.c_int, [H, _I64P, _I32P]),
@@ -237,7 +241,10 @@ class Preconditioner:
         if comm is not None:
             comm.attach(self)
             px, py, pz = rank_grid
-            self._check(self._lib.hymls_mi_set_comm(self._h, C.byref(comm.c_struct), px, py, pz))
+            if getattr(comm, "nccl_comm", None) is not None:   # built-in RCCL transport (hymls_amd.dist.RcclComm)
+                self._check(self._lib.hymls_mi_set_comm_rccl(self._h, comm.nccl_comm, px, py, pz))
+            else:
+                self._check(self._lib.hymls_mi_set_comm(self._h, C.byref(comm.c_struct), px, py, pz))
         if K is not None:
             self.SetMatrix(K)
         if testVector is not None:

@@ -16,6 +16,7 @@ using namespace hymls;
 struct hymls_mi {
   Params p;
   int device = 0;
+  dev::Context* ctx = nullptr;   // this handle's streams, arenas, timers (bound at every entry below)
   Csr K;
   bool have_matrix = false;
   Comm comm;                 // one rank unless hymls_mi_set_comm was called
@@ -40,7 +41,7 @@ static double now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-#define API_BEGIN try {
+#define API_BEGIN try { dev::bind(h->ctx);
 #define API_END(h)                                                   \
   }                                                                  \
   catch (const hymls::Error& e) { if (h) (h)->err = e.what(); return e.code; } \
@@ -96,7 +97,7 @@ int hymls_mi_create(hymls_mi_t** out, const hymls_mi_params* q, int device) {
   API_BEGIN
   h->p = convert(q);
   h->device = device;
-  dev::init(device);
+  h->ctx = dev::create_context(device);
   API_END(h)
 }
 
@@ -130,10 +131,36 @@ int hymls_mi_set_comm(hymls_mi_t* h, const hymls_mi_comm* c, int px, int py, int
   HYMLS_CHECK(c->size >= 1 && c->rank >= 0 && c->rank < c->size && px * py * pz == c->size, -2,
               "rank grid px*py*pz must equal the number of ranks");
   HYMLS_CHECK(c->size == 1 || (c->alltoallv && c->alloc), -2, "a sharded run needs both transport callbacks");
+  h->comm.release();   // (a built-in transport attached earlier)
   h->comm.rank = c->rank; h->comm.size = c->size; h->comm.ctx = c->ctx;
   h->comm.px = px; h->comm.py = py; h->comm.pz = pz;
   h->comm.alltoallv = c->alltoallv; h->comm.alloc = c->alloc;
   h->comm.force = c->size == 1 && c->alltoallv && c->alloc && std::getenv("HYMLS_MI_FORCE_SHARDED") != nullptr;
+  h->top.reset(); h->initialized = false; h->computed = false; h->have_matrix = false;
+  API_END(h)
+}
+
+int hymls_mi_rccl_unique_id(char* id128) {
+  if (!id128) return -2;
+  try { rccl_unique_id(id128); } catch (const hymls::Error& e) { return e.code; } catch (...) { return -3; }
+  return 0;
+}
+
+int hymls_mi_rccl_comm_init(const char* id128, int rank, int size, int device, void** nccl_comm) {
+  if (!id128 || !nccl_comm || size < 1 || rank < 0 || rank >= size) return -2;
+  try { *nccl_comm = rccl_init(id128, rank, size, device); } catch (const hymls::Error& e) { return e.code; } catch (...) { return -3; }
+  return 0;
+}
+
+void hymls_mi_rccl_comm_destroy(void* nccl_comm) { try { rccl_destroy(nccl_comm); } catch (...) {} }
+
+int hymls_mi_set_comm_rccl(hymls_mi_t* h, void* nccl_comm, int px, int py, int pz) {
+  if (!h || !nccl_comm) return -2;
+  API_BEGIN
+  rccl_attach(h->comm, nccl_comm, /*owns=*/false);
+  HYMLS_CHECK(px * py * pz == h->comm.size, -2, "rank grid px*py*pz must equal the number of ranks of the communicator");
+  h->comm.px = px; h->comm.py = py; h->comm.pz = pz;
+  h->comm.force = h->comm.size == 1 && std::getenv("HYMLS_MI_FORCE_SHARDED") != nullptr;
   h->top.reset(); h->initialized = false; h->computed = false; h->have_matrix = false;
   API_END(h)
 }
@@ -394,6 +421,7 @@ double hymls_mi_last_apply_seconds(const hymls_mi_t* hc, int which) {
   // average seconds per ApplyInverse of phase `which` since profiling was switched on
   try {
     double sum[8] = {0}; int cnt[8] = {0};
+    dev::bind(h->ctx);
     dev::profile_collect(sum, cnt);
     for (int i = 0; i < 8; i++) { h->prof_sum[i] += sum[i]; h->prof_cnt[i] += cnt[i]; }
   } catch (...) { return 0; }
@@ -403,11 +431,14 @@ int hymls_mi_set_profiling(hymls_mi_t* h, int on) {
   if (!h) return -2;
   h->profiling = on != 0;
   for (int i = 0; i < 8; i++) { h->prof_sum[i] = 0; h->prof_cnt[i] = 0; }
-  try { double s[8] = {0}; int c[8] = {0}; dev::profile_collect(s, c); } catch (...) {}
+  try { double s[8] = {0}; int c[8] = {0}; dev::bind(h->ctx); dev::profile_collect(s, c); } catch (...) {}
   if (h->top) h->top->profiling = h->profiling;
   return 0;
 }
-void* hymls_mi_stream(const hymls_mi_t*) { return dev::stream(); }
+void* hymls_mi_stream(const hymls_mi_t* h) {
+  if (!h || !h->ctx) return nullptr;
+  try { dev::bind(h->ctx); return dev::stream(); } catch (...) { return nullptr; }
+}
 
 int hymls_mi_get_interior(const hymls_mi_t* h, int level, int sd, int32_t* n, int32_t* nodes) {
   if (!h || !h->top) return -1;
@@ -489,8 +520,11 @@ const char* hymls_mi_last_error(const hymls_mi_t* h) { return h ? h->err.c_str()
 void hymls_mi_destroy(hymls_mi_t* h) {
   if (!h) return;
   try {
+    dev::bind(h->ctx);
     h->top.reset();
     dev::free(h->d_b); dev::free(h->d_x);
+    h->comm.release();
+    dev::destroy_context(h->ctx);
   } catch (...) {}
   delete h;
 }

@@ -8,7 +8,7 @@ void Comm::a2a_host(const void* send, const std::vector<int64_t>& scnt, void* re
                     int elem_bytes) const {
   HYMLS_CHECK(alltoallv != nullptr, -2, "sharded run without a transport (hymls_mi_set_comm)");
   const int ierr = alltoallv(ctx, send, scnt.data(), recv, rcnt.data(), elem_bytes, 0);
-  HYMLS_CHECK(ierr == 0, -3, "host all-to-all failed in the transport callback");
+  HYMLS_CHECK(ierr == 0, -3, std::string("host all-to-all failed in the transport ") + rccl_last_error(*this));
 }
 
 std::vector<int64_t> Comm::exchange_counts(const std::vector<int64_t>& scnt) const {
@@ -31,6 +31,12 @@ void Comm::allsum(std::vector<double>& v) const {
   std::vector<double> all = allgather(v);
   const size_t m = v.size();
   for (size_t i = 0; i < m; i++) { double s = 0.0; for (int q = 0; q < size; q++) s += all[(size_t)q * m + i]; v[i] = s; }
+}
+
+void Comm::release() {
+  if (release_fn && ctx) { release_fn(ctx); ctx = nullptr; alltoallv = nullptr; alloc = nullptr; }
+  release_fn = nullptr; native = false;
+  sarena_ = rarena_ = nullptr; scap_ = rcap_ = 0;
 }
 
 static double* grow(const Comm& c, double*& arena, int64_t& cap, int64_t need) {
@@ -79,7 +85,7 @@ void Exchange::forward(const double* src, double* dst) const {
   double* rb = comm->recv_arena(nrecv);
   if (nsend) dev::gather(nsend, d_sidx, src, sb);
   const int ierr = comm->alltoallv(comm->ctx, sb, scnt.data(), rb, rcnt.data(), (int32_t)sizeof(double), 1);
-  HYMLS_CHECK(ierr == 0, -3, "device all-to-all failed in the transport callback");
+  HYMLS_CHECK(ierr == 0, -3, std::string("device all-to-all failed in the transport ") + rccl_last_error(*comm));
   if (nrecv) dev::scatter(nrecv, d_ridx, rb, dst);
 }
 
@@ -89,7 +95,7 @@ void Exchange::backward(const double* src, double* dst, bool add) const {
   double* rb = comm->recv_arena(nsend);
   if (nrecv) dev::gather(nrecv, d_ridx, src, sb);
   const int ierr = comm->alltoallv(comm->ctx, sb, rcnt.data(), rb, scnt.data(), (int32_t)sizeof(double), 1);
-  HYMLS_CHECK(ierr == 0, -3, "device all-to-all failed in the transport callback");
+  HYMLS_CHECK(ierr == 0, -3, std::string("device all-to-all failed in the transport ") + rccl_last_error(*comm));
   if (!nsend) return;
   if (!add) { dev::scatter(nsend, d_sidx, rb, dst); return; }
   // peer by peer (a position may get contributions from several peers): fixed order of the additions

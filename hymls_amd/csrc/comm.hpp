@@ -24,6 +24,11 @@ struct Comm {
   // exchange arena the transport can address (a torch tensor in the Python mirror)
   void* (*alloc)(void* ctx, int64_t bytes) = nullptr;
 
+  // built-in RCCL transport (comm_rccl.cpp): ctx is owned by the communicator and released through release_fn
+  void (*release_fn)(void* ctx) = nullptr;
+  bool native = false;
+  void release();               // free what the transport owns (arenas, staging buffers, its ncclComm); idempotent
+
   bool force = false;           // treat a single rank as sharded (exercises the transport with self-exchanges)
   bool distributed() const { return size > 1 || force; }
 
@@ -79,6 +84,13 @@ struct Comm {
   mutable double *sarena_ = nullptr, *rarena_ = nullptr;
   mutable int64_t scap_ = 0, rcap_ = 0;
 };
+
+// built-in transport on RCCL (product library only; the test-only host simulator has stubs that fail with -99)
+void rccl_unique_id(char* id128);                       // ncclGetUniqueId (call on one rank, hand the bytes to the others)
+void* rccl_init(const char* id128, int rank, int size, int device); // ncclCommInitRank on `device` -> ncclComm_t (collective)
+void rccl_destroy(void* nccl_comm);
+void rccl_attach(Comm& c, void* nccl_comm, bool owns);  // point c's callbacks at RCCL send/recv groups on the handle's stream
+const char* rccl_last_error(const Comm& c);
 
 // persistent plan of one vector exchange: dst[ridx[k]] on this rank = src[sidx[...]] on the peer
 struct Exchange {

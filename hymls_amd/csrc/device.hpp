@@ -11,8 +11,14 @@ namespace hymls {
 namespace dev {
 
 // ---- runtime
-void init(int device);                 // select device, create stream
-void* stream();                        // hipStream_t (nullptr in the simulator)
+// per-handle device context (device ordinal, streams, setup arenas, timers, profiling marks).  Every C-ABI entry binds
+// the handle's context on the calling thread before it touches the device; nothing device-related is process-global.
+struct Context;
+Context* create_context(int device);   // throws -3 without a HIP device, -2 for a bad ordinal
+void bind(Context* c);                 // make c current on this thread (selects its device); nullptr: unbind
+void destroy_context(Context* c);
+void* stream();                        // hipStream_t of the bound context (nullptr in the simulator)
+const double* zeros16();               // 16 device zeros (bound context)
 void* alloc(size_t bytes);
 void free(void* p);
 void h2d(void* dst, const void* src, size_t bytes);

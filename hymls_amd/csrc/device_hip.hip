@@ -37,42 +37,85 @@ namespace dev {
                                    __FILE__ + ":" + std::to_string(__LINE__));             \
   } while (0)
 
-static hipStream_t g_stream = nullptr;      // the stream every launcher uses (main or one of the side streams)
-static hipStream_t g_main = nullptr, g_side[NSIDE];
-static hipEvent_t g_fork_ev, g_join_ev[NSIDE];
-static int g_cur = 0;
-static bool g_side_init = false;
-static bool g_init = false;
-static hipEvent_t g_ev[16][2];
-static bool g_ev_init = false;
+// ---- per-handle device context: device ordinal, the stream every launcher uses (main or one of the side streams),
+// side streams and their events, setup arenas (one per stream), timers, profiling marks and small scratch buffers.
+// A handle binds its context at every API entry (capi.cpp); nothing device-related is process-global, so any number
+// of preconditioners (on the same or on different devices) can live in one process, as in the reference.
+struct MarkRec { int phase; bool begin; hipEvent_t ev; };
+struct Context {
+  int device = 0;
+  hipStream_t cur = nullptr, main = nullptr, side[NSIDE] = {};
+  hipEvent_t fork_ev = nullptr, join_ev[NSIDE] = {};
+  int cur_idx = 0;
+  bool side_init = false;
+  void* arena[NSIDE + 1] = {};
+  size_t arena_cap[NSIDE + 1] = {};
+  hipEvent_t ev[16][2] = {};
+  bool ev_init = false;
+  std::vector<MarkRec> marks;
+  std::vector<hipEvent_t> pool;
+  double* dpart = nullptr;     // partial sums of dot()
+  double* zeros = nullptr;     // 16 zeros
+  bool big_attr_set = false;
+};
+static thread_local Context* t_ctx = nullptr;
+static inline Context& ctx() {
+  if (!t_ctx) throw Error(-3, "no device context bound (internal error: API entry without dev::bind)");
+  return *t_ctx;
+}
+#define g_stream (ctx().cur)
 
-void init(int device) {
+Context* create_context(int device) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0)
     throw Error(-3, "no HIP device available: hymls_amd needs an AMD GPU (there is no CPU fallback)");
+  if (device < 0 || device >= count) throw Error(-2, "HIP device ordinal out of range");
   HIP_CHECK(hipSetDevice(device));
-  if (!g_init) {
-    HIP_CHECK(hipStreamCreate(&g_stream));
-    g_main = g_stream;
-    g_init = true;
-  }
+  Context* c = new Context();
+  c->device = device;
+  hipError_t es = hipStreamCreate(&c->main);
+  if (es != hipSuccess) { delete c; HIP_CHECK(es); }
+  c->cur = c->main;
+  return c;
 }
-void* stream() { return (void*)g_main; }
+void bind(Context* c) {
+  t_ctx = c;
+  if (c) HIP_CHECK(hipSetDevice(c->device));
+}
+void destroy_context(Context* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->main);
+  for (int k = 0; k <= NSIDE; k++) if (c->arena[k]) (void)hipFree(c->arena[k]);
+  if (c->dpart) (void)hipFree(c->dpart);
+  if (c->zeros) (void)hipFree(c->zeros);
+  for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
+  for (auto& e : c->pool) (void)hipEventDestroy(e);
+  if (c->ev_init) for (auto& e : c->ev) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
+  if (c->side_init) {
+    for (int k = 0; k < NSIDE; k++) { (void)hipStreamSynchronize(c->side[k]); (void)hipStreamDestroy(c->side[k]); (void)hipEventDestroy(c->join_ev[k]); }
+    (void)hipEventDestroy(c->fork_ev);
+  }
+  (void)hipStreamDestroy(c->main);
+  if (t_ctx == c) t_ctx = nullptr;
+  delete c;
+}
+void* stream() { return (void*)ctx().main; }
 void fork_streams() {
-  if (!g_side_init) {
-    for (int k = 0; k < NSIDE; k++) { HIP_CHECK(hipStreamCreate(&g_side[k])); HIP_CHECK(hipEventCreateWithFlags(&g_join_ev[k], hipEventDisableTiming)); }
-    HIP_CHECK(hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming));
-    g_side_init = true;
+  Context& c = ctx();
+  if (!c.side_init) {
+    for (int k = 0; k < NSIDE; k++) { HIP_CHECK(hipStreamCreate(&c.side[k])); HIP_CHECK(hipEventCreateWithFlags(&c.join_ev[k], hipEventDisableTiming)); }
+    HIP_CHECK(hipEventCreateWithFlags(&c.fork_ev, hipEventDisableTiming));
+    c.side_init = true;
   }
-  HIP_CHECK(hipEventRecord(g_fork_ev, g_main));
-  for (int k = 0; k < NSIDE; k++) HIP_CHECK(hipStreamWaitEvent(g_side[k], g_fork_ev, 0));
+  HIP_CHECK(hipEventRecord(c.fork_ev, c.main));
+  for (int k = 0; k < NSIDE; k++) HIP_CHECK(hipStreamWaitEvent(c.side[k], c.fork_ev, 0));
 }
-void use_stream(int k) { g_cur = k; g_stream = k == 0 ? g_main : g_side[k - 1]; }
-static void* g_arena[NSIDE + 1] = {nullptr};     // setup scratch, one arena per stream
-static size_t g_arena_cap[NSIDE + 1] = {0};
+void use_stream(int k) { Context& c = ctx(); c.cur_idx = k; c.cur = k == 0 ? c.main : c.side[k - 1]; }
 void join_streams() {
-  for (int k = 0; k < NSIDE; k++) { HIP_CHECK(hipEventRecord(g_join_ev[k], g_side[k])); HIP_CHECK(hipStreamWaitEvent(g_main, g_join_ev[k], 0)); }
+  Context& c = ctx();
+  for (int k = 0; k < NSIDE; k++) { HIP_CHECK(hipEventRecord(c.join_ev[k], c.side[k])); HIP_CHECK(hipStreamWaitEvent(c.main, c.join_ev[k], 0)); }
   use_stream(0);   // (the side arenas stay allocated: re-allocating them costs about a second per Compute at 256^3)
 }
 void* alloc(size_t bytes) {
@@ -98,45 +141,53 @@ void d2d(void* d, const void* s, size_t n) {
 void zero(void* d, size_t n) { if (n) HIP_CHECK(hipMemsetAsync(d, 0, n, g_stream)); }
 void sync() { HIP_CHECK(hipStreamSynchronize(g_stream)); }
 void* shared_scratch(size_t bytes) {
-  if (bytes > g_arena_cap[g_cur]) {
+  Context& c = ctx();
+  const int k = c.cur_idx;
+  if (bytes > c.arena_cap[k]) {
     sync();
-    if (g_arena[g_cur]) (void)hipFree(g_arena[g_cur]);
-    g_arena[g_cur] = nullptr; g_arena_cap[g_cur] = 0;
-    g_arena[g_cur] = alloc(bytes);
-    g_arena_cap[g_cur] = bytes;
+    if (c.arena[k]) (void)hipFree(c.arena[k]);
+    c.arena[k] = nullptr; c.arena_cap[k] = 0;
+    c.arena[k] = alloc(bytes);
+    c.arena_cap[k] = bytes;
   }
-  return g_arena[g_cur];
+  return c.arena[k];
+}
+const double* zeros16() {
+  Context& c = ctx();
+  if (!c.zeros) { c.zeros = (double*)alloc(16 * sizeof(double)); zero(c.zeros, 16 * sizeof(double)); }
+  return c.zeros;
 }
 size_t mem_free() { size_t f = 0, t = 0; HIP_CHECK(hipMemGetInfo(&f, &t)); return f; }
 void timer_start(int id) {
-  if (!g_ev_init) {
-    for (auto& e : g_ev) { HIP_CHECK(hipEventCreate(&e[0])); HIP_CHECK(hipEventCreate(&e[1])); }
-    g_ev_init = true;
+  Context& c = ctx();
+  if (!c.ev_init) {
+    for (auto& e : c.ev) { HIP_CHECK(hipEventCreate(&e[0])); HIP_CHECK(hipEventCreate(&e[1])); }
+    c.ev_init = true;
   }
-  HIP_CHECK(hipEventRecord(g_ev[id][0], g_stream));
+  HIP_CHECK(hipEventRecord(c.ev[id][0], g_stream));
 }
 double timer_stop(int id) {
-  HIP_CHECK(hipEventRecord(g_ev[id][1], g_stream));
-  HIP_CHECK(hipEventSynchronize(g_ev[id][1]));
+  Context& c = ctx();
+  HIP_CHECK(hipEventRecord(c.ev[id][1], g_stream));
+  HIP_CHECK(hipEventSynchronize(c.ev[id][1]));
   float ms = 0;
-  HIP_CHECK(hipEventElapsedTime(&ms, g_ev[id][0], g_ev[id][1]));
+  HIP_CHECK(hipEventElapsedTime(&ms, c.ev[id][0], c.ev[id][1]));
   return 1e-3 * ms;
 }
 
-struct MarkRec { int phase; bool begin; hipEvent_t ev; };
-static std::vector<MarkRec> g_marks;
-static std::vector<hipEvent_t> g_pool;
 void mark(int phase, bool begin) {
+  Context& c = ctx();
   hipEvent_t e;
-  if (!g_pool.empty()) { e = g_pool.back(); g_pool.pop_back(); }
+  if (!c.pool.empty()) { e = c.pool.back(); c.pool.pop_back(); }
   else HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipEventRecord(e, g_stream));
-  g_marks.push_back({phase, begin, e});
+  c.marks.push_back({phase, begin, e});
 }
 void profile_collect(double* sum, int* cnt) {
+  Context& c = ctx();
   HIP_CHECK(hipStreamSynchronize(g_stream));
   hipEvent_t open[8] = {};
-  for (auto& m : g_marks) {
+  for (auto& m : c.marks) {
     if (m.begin) open[m.phase] = m.ev;
     else if (open[m.phase]) {
       float ms = 0;
@@ -145,8 +196,8 @@ void profile_collect(double* sum, int* cnt) {
       cnt[m.phase]++;
     }
   }
-  for (auto& m : g_marks) g_pool.push_back(m.ev);
-  g_marks.clear();
+  for (auto& m : c.marks) c.pool.push_back(m.ev);
+  c.marks.clear();
 }
 
 static inline void launch_check() { HIP_CHECK(hipGetLastError()); }
@@ -763,10 +814,9 @@ __global__ void k_big_root_update(PlanD P, BatchD B, FrontD F) {
 void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD* kids, int32_t nkids, int32_t b0,
                       int32_t nbc, const double* kval) {
   if (nbc <= 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!ctx().big_attr_set) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_big_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((PIECE * PIECE + PIECE) * sizeof(double))));
-    attr_set = true;
+    ctx().big_attr_set = true;
   }
   if (nbc > 65535) throw Error(-3, "too many batch members for the big-front path");
   const int w = F.w, ri = F.ri, rs = F.rs, m = w + ri + rs;
@@ -1275,7 +1325,7 @@ __global__ void __launch_bounds__(256) k_dot_partial(int64_t n, const double* __
 }
 double dot(int64_t n, const double* x, const double* y) {
   if (n <= 0) return 0.0;
-  static double* dpart = nullptr;
+  double*& dpart = ctx().dpart;
   if (!dpart) dpart = (double*)alloc(1024 * sizeof(double));
   const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
   hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, g_stream, n, x, y, dpart);

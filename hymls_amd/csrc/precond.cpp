@@ -292,9 +292,7 @@ void DirectSolver::solve(const double* b, double* x, bool zero_fixed) {
   dev::gather(n_, d_perm_, b, d_z_);
   if (zero_fixed && !fix_lids_.empty()) {
     // zero the Dirichlet right-hand sides: scatter zeros
-    static thread_local double* zeros = nullptr;
-    if (!zeros) { zeros = (double*)dev::alloc(16 * sizeof(double)); dev::zero(zeros, 16 * sizeof(double)); }
-    dev::scatter((int64_t)fix_lids_.size(), d_fix_, zeros, d_z_);
+    dev::scatter((int64_t)fix_lids_.size(), d_fix_, dev::zeros16(), d_z_);
   }
   lu_->solve(d_z_);
   dev::scatter(n_, d_perm_, d_z_, x);
@@ -1318,7 +1316,7 @@ void LevelSolver::exchange_records() {
   int64_t off = 0;
   for (auto& sg : rec_send_) { dev::d2d(sb + off, d_ext_ + sg.off, (size_t)sg.len * sizeof(double)); off += sg.len; }
   const int ierr = comm_->alltoallv(comm_->ctx, sb, rec_scnt_.data(), rb, rec_rcnt_.data(), (int32_t)sizeof(double), 1);
-  HYMLS_CHECK(ierr == 0, -3, "device all-to-all failed in the transport callback");
+  HYMLS_CHECK(ierr == 0, -3, std::string("device all-to-all failed in the transport ") + rccl_last_error(*comm_));
   if (rec_nrecv_) dev::d2d(d_ext_ + ext_recv_base_, rb, (size_t)rec_nrecv_ * sizeof(double));
 }
 
@@ -1421,6 +1419,7 @@ void LevelSolver::compute() {
   // ---- interior factorisations + separator blocks, class by class, chunk by chunk.  The coarser levels have many
   // classes with one or two large subdomains each: their launch chains are independent and run on side streams
   const bool side = level_ >= 1 && cls_.size() > 1 && !std::getenv("HYMLS_MI_NO_SIDE_STREAMS");
+  struct MainStreamGuard { ~MainStreamGuard() { try { dev::use_stream(0); } catch (...) {} } } back_to_main;   // also when a launch throws
   if (side) dev::fork_streams();
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];

@@ -70,6 +70,45 @@ def transport_selftest(device, backend):
     return None
 
 
+class RcclComm:
+    """The library's built-in transport (include/hymls_mi.h: hymls_mi_set_comm_rccl; hymls_amd/csrc/comm_rccl.cpp): RCCL
+    send/recv groups on the handle's stream, no Python in ApplyInverse.  This class only bootstraps the ncclComm_t:
+    rank 0 draws the unique id, torch.distributed (any backend, host tensors over gloo or device tensors over nccl)
+    broadcasts its 128 bytes, every rank calls ncclCommInitRank through the library.  Without torch.distributed
+    (rank = 0, size = 1) the communicator has a single rank."""
+
+    def __init__(self, device_index=0, lib=None, group=None):
+        from .api import load_library
+        self._lib = lib or load_library()
+        use_dist = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if use_dist else 0
+        self.size = dist.get_world_size(group) if use_dist else 1
+        idbuf = C.create_string_buffer(128)
+        if self.rank == 0:
+            ierr = self._lib.hymls_mi_rccl_unique_id(idbuf)
+            if ierr:
+                raise RuntimeError("hymls_mi_rccl_unique_id failed (%d)" % ierr)
+        if use_dist and self.size > 1:
+            on_dev = dist.get_backend(group) == "nccl"
+            t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=torch.device("cuda", device_index) if on_dev else "cpu")
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        comm = C.c_void_p()
+        ierr = self._lib.hymls_mi_rccl_comm_init(idbuf, self.rank, self.size, device_index, C.byref(comm))
+        if ierr:
+            raise RuntimeError("hymls_mi_rccl_comm_init failed (%d)" % ierr)
+        self.nccl_comm = comm
+        self.error = None
+
+    def attach(self, prec):
+        self._prec = prec
+
+    def close(self):
+        if self.nccl_comm is not None:
+            self._lib.hymls_mi_rccl_comm_destroy(self.nccl_comm)
+            self.nccl_comm = None
+
+
 class TorchComm:
     """device: torch.device of this rank's buffers ('cpu' with the test-only host simulator).
     device_group: process group for device buffers (default group); host_group: gloo group for

@@ -88,6 +88,20 @@ typedef struct hymls_mi_comm {
 /* rank r owns the box (r % px, (r / px) % py, r / (px*py)) of the grid, as the reference's
  * CreatePIDMap (src/HYMLS_BasePartitioner.cpp:361-586); call before any matrix is set.  Collective. */
 int hymls_mi_set_comm(hymls_mi_t* h, const hymls_mi_comm* comm, int px, int py, int pz);
+/* The built-in transport: RCCL send/recv groups on the handle's stream (hymls_amd/csrc/comm_rccl.cpp) -- the
+ * "RCCL halo/separator exchange over xGMI replacing the Epetra MPI Import/Export" (reference
+ * src/HYMLS_Preconditioner.cpp:978-979,1050-1052, src/HYMLS_SchurPreconditioner.cpp:1076-1078).  One exchange of the
+ * library = one ncclGroupStart / ncclSend.. / ncclRecv.. / ncclGroupEnd; no host code runs inside ApplyInverse.
+ *   rank 0:      hymls_mi_rccl_unique_id(id);  hand the 128 bytes to every rank (MPI_Bcast, torch.distributed, a file)
+ *   every rank:  hymls_mi_rccl_comm_init(id, rank, size, device, &c);  (collective: ncclCommInitRank)
+ *                hymls_mi_set_comm_rccl(h, c, px, py, pz);             (instead of hymls_mi_set_comm; c is borrowed
+ *                and may serve several handles: an ncclComm_t the application already owns works the same way)
+ *                ... hymls_mi_destroy(h); hymls_mi_rccl_comm_destroy(c);
+ * Returns -3 when librccl cannot be loaded; -99 from the test-only host simulator. */
+int hymls_mi_rccl_unique_id(char* id128);
+int hymls_mi_rccl_comm_init(const char* id128, int rank, int size, int device, void** nccl_comm);
+void hymls_mi_rccl_comm_destroy(void* nccl_comm);
+int hymls_mi_set_comm_rccl(hymls_mi_t* h, void* nccl_comm /* ncclComm_t */, int px, int py, int pz);
 /* the rows this rank has to be given: interiors and separators of its subdomains (the overlapping
  * row map of the reference).  Two-call protocol (gids == NULL: count only); ascending gids. */
 int hymls_mi_required_rows(hymls_mi_t* h, int64_t* n, int32_t* gids);

@@ -22,7 +22,10 @@ def main():
     eq, nx, ny, nz, sx, levels, cx, part, mode = sys.argv[1:10]
     nx, ny, nz, sx, levels, cx = int(nx), int(ny), int(nz), int(sx), int(levels), int(cx)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if mode == "gpu-nccl":     # one rank per GPU over RCCL (a single rank exchanges with itself: HYMLS_MI_FORCE_SHARDED)
+    if mode == "gpu-rccl":     # built-in transport of the library (comm_rccl.cpp); torch.distributed (gloo) only hands out the id
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend="gloo")
+    elif mode == "gpu-nccl":   # one rank per GPU over RCCL (a single rank exchanges with itself: HYMLS_MI_FORCE_SHARDED)
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
     else:
@@ -34,6 +37,9 @@ def main():
         from hymls_amd.dist import transport_selftest
         err = transport_selftest(device, "nccl")
         assert err is None, err
+    elif mode == "gpu-rccl":
+        lib = hymls_amd.load_library()
+        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
     elif mode == "hostsim":
         lib = hymls_amd.load_library(os.path.join(ROOT, "tests", "hostsim", "libhymls_mi_hostsim.so"))
         device = "cpu"
@@ -45,9 +51,13 @@ def main():
         prec["Coarsening Factor"] = cx
     prm = {"Problem": {"Equations": eq, "Dimension": 3, "nx": nx, "ny": ny, "nz": nz}, "Preconditioner": prec}
     a = float(nx * nx)
-    comm = TorchComm(device)
+    if mode == "gpu-rccl":
+        from hymls_amd.dist import RcclComm
+        comm = RcclComm(int(os.environ.get("LOCAL_RANK", "0")), lib=lib)
+    else:
+        comm = TorchComm(device)
     P = hymls_amd.Preconditioner(None, prm, lib=lib, comm=comm, rank_grid=rank_grid(world),
-                                 device=int(os.environ.get("LOCAL_RANK", "0")) if mode == "gpu-nccl" else 0)
+                                 device=int(os.environ.get("LOCAL_RANK", "0")) if mode in ("gpu-nccl", "gpu-rccl") else 0)
     req = P.RequiredRows()
     rows = hymls_amd.generate_rows(eq, nx, ny, nz, req, a=a, lib=lib)
     P.SetMatrixRows(req, rows)

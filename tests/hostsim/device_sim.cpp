@@ -6,14 +6,25 @@
 // ONLY into tests/hostsim/libhymls_mi_hostsim.so; the product library libhymls_mi.so
 // contains the HIP implementation (device_hip.hip) and no CPU path.
 #include "device.hpp"
+#include "comm.hpp"
 #include <cstring>
 #include <chrono>
 
 namespace hymls {
+// the built-in RCCL transport does not exist in the simulator
+void rccl_unique_id(char*) { throw Error(-99, "the host simulator has no RCCL transport"); }
+void* rccl_init(const char*, int, int, int) { throw Error(-99, "the host simulator has no RCCL transport"); }
+void rccl_destroy(void*) {}
+void rccl_attach(Comm&, void*, bool) { throw Error(-99, "the host simulator has no RCCL transport"); }
+const char* rccl_last_error(const Comm&) { return ""; }
 namespace dev {
 
-void init(int) {}
+struct Context { int device; };
+Context* create_context(int device) { return new Context{device}; }
+void bind(Context*) {}
+void destroy_context(Context* c) { delete c; }
 void* stream() { return nullptr; }
+const double* zeros16() { static const double z[16] = {0}; return z; }
 void* alloc(size_t bytes) { return std::calloc(std::max<size_t>(bytes, 8), 1); }
 void free(void* p) { std::free(p); }
 void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }

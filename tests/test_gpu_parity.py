@@ -310,6 +310,41 @@ def test_sharded_transport_over_rccl_single_rank(gpu_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [("Stokes-C", 32, 32, 32, 4, 2, 2, "Skew Cartesian"), ("Laplace", 32, 32, 32, 4, 1, -1, "Cartesian")])
+def test_builtin_rccl_transport_single_rank(gpu_lib, case):
+    """the library's own transport (hymls_mi_set_comm_rccl: ncclSend / ncclRecv groups on the handle's stream, no
+    Python frame inside ApplyInverse): one rank forced onto the sharded code path, every exchange is a self-exchange
+    through the transport (ncclCommInitRank with one rank, device-to-device self segment, staged host exchanges).
+    Results against the one-rank handle; a sharded K x and SetMatrix + recompute included."""
+    from test_sharded import run_worker
+    res = run_worker(1, case, "gpu-rccl", 29553, timeout=600, env_extra={"HYMLS_MI_FORCE_SHARDED": "1"})
+    assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
+    assert res["rel_err"] < 1e-10 and res["repeat_diff"] == 0.0 and res["matvec_err"] < 1e-13
+
+
+@pytest.mark.gpu
+def test_two_live_handles_alternate(gpu_lib):
+    """every handle owns its device context (stream, arenas, profiling marks): two preconditioners alive at the same
+    time, applied alternately, give exactly what each gives alone (reference: any number of Preconditioner objects)."""
+    A1, tv1 = problem("Laplace", 16)
+    A2, tv2 = problem("Stokes-C", 16)
+    prm1, prm2 = xml_params("Laplace", 16, 4, 2, cx=2), xml_params("Stokes-C", 16, 8, 1, partitioner="Skew Cartesian")
+    b1 = np.random.default_rng(3).uniform(-1, 1, A1.shape[0]); b2 = np.random.default_rng(4).uniform(-1, 1, A2.shape[0])
+    P1 = product_prec(A1, tv1, prm1, gpu_lib); x1 = P1.ApplyInverse(b1); del P1
+    P2 = product_prec(A2, tv2, prm2, gpu_lib); x2 = P2.ApplyInverse(b2); del P2
+    Pa = product_prec(A1, tv1, prm1, gpu_lib)
+    Pb = product_prec(A2, tv2, prm2, gpu_lib)
+    assert Pa.stream() != Pb.stream()
+    Pa.set_profiling(True)
+    for _ in range(3):
+        assert np.array_equal(Pa.ApplyInverse(b1), x1)
+        assert np.array_equal(Pb.ApplyInverse(b2), x2)
+    Pb.Compute()                                   # setup of one handle between applies of the other
+    assert np.array_equal(Pa.ApplyInverse(b1), x1) and np.array_equal(Pb.ApplyInverse(b2), x2)
+    assert Pa.last_apply_seconds(0) > 0 and Pb.last_apply_seconds(0) == 0     # profiling marks are per handle
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("re,part,levels,its_max", [("re1000", "Cartesian", 1, 100), ("re1000", "Skew Cartesian", 1, 110), ("re1000", "Cartesian", 2, 120)])
 def test_reference_driven_cavity_2d_gpu(gpu_lib, re, part, levels, its_max):
     """the reference's 2D driven-cavity Jacobian at Re 1000 (its own test data) on the GPU path"""

@@ -114,7 +114,7 @@ def drop_by_value(A, droptol=SMALL, kind="RelZeroDiag"):
 class CoarseSolver:
     """src/HYMLS_CoarseSolver.cpp:131-323 (plain, un-bordered path)."""
 
-    def __init__(self, S, gids, fix_gids):
+    def __init__(self, S, gids, fix_gids, permc_spec=None):
         self.gids = np.asarray(gids)
         S = drop_by_value(S, SMALL, "RelFullDiag").tolil()
         self.fix_lids = []
@@ -130,7 +130,8 @@ class CoarseSolver:
             self.fix_lids.append(lid)
         self.S = S.tocsc()
         self.n = self.S.shape[0]
-        self.lu = spla.splu(self.S) if self.n else None
+        # (permc_spec: SuperLU column ordering; the values of the exact LU are unpinned by the reference's tests)
+        self.lu = (spla.splu(self.S, permc_spec=permc_spec) if permc_spec else spla.splu(self.S)) if self.n else None
         self.border = None
 
     def set_border(self, V, W, C):

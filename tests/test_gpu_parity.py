@@ -2,6 +2,8 @@
 Tolerances: FP64, different LU (multifrontal without pivoting, product-form panels vs
 SuperLU/LAPACK in the oracle) => relative 2-norm difference of one ApplyInverse
 <= 1e-10 for exact (levels=0) configurations and <= 1e-8 multilevel."""
+import os
+
 import numpy as np
 import pytest
 
@@ -273,6 +275,32 @@ def full_size_properties(gpu_lib, problem, n, levels, re=0.0, max_its=400, sizes
     print("GMRES(%s %d^3 re=%g, Number of Levels=%d): %d iterations, true relative residual %.2e" % (problem, n, re, levels, its, true_rel))
     assert its < max_its and true_rel < 1e-7
     return its
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,levels,re", [("Stokes", 48, 1, 0.0), ("Cavity", 48, 1, 375.0), ("Darcy", 48, 1, 0.0), ("Stokes", 32, 2, 0.0)])
+def test_values_against_the_compiled_cpu_oracle(gpu_lib, kind, n, levels, re):
+    """ApplyInverse VALUES (not only iteration counts) of the multilevel method at sizes the numpy oracle cannot reach
+    in test time: the GPU path against the compiled CPU oracle (oracle/cpu_oracle.py, pinned to the numpy oracle by
+    tests/test_cpu_oracle.py) on the same matrix and right-hand sides.  48^3 (442 k DoF) two-level for the three
+    BASELINE problem families (cavity: the cell Peclet number of Re = 1000 on 128^3), 32^3 three-level (cx = 2)."""
+    import hymls_amd
+    from oracle import galeri, cpu_oracle
+    A = {"Stokes": lambda: galeri.stokes3d(n, n, n), "Darcy": lambda: galeri.darcy3d(n, n, n, 1.0, -1.0),
+         "Cavity": lambda: galeri.oseen3d(n, n, n, re)}[kind]()
+    rp, ci, va = hymls_amd.generate_problem(kind, n, n, n, re=re, lib=gpu_lib)
+    assert np.array_equal(rp, A.indptr) and np.array_equal(ci, A.indices) and np.array_equal(va, A.data)
+    tv = galeri.create_testvector(A)
+    sx, cx = (8, -1) if levels == 1 else (4, 2)
+    P = product_prec(A, tv, xml_params("Stokes-C", n, sx, levels, cx=cx, partitioner="Skew Cartesian"), gpu_lib)
+    from oracle.partition import Params
+    p = Params(nx=n, ny=n, nz=n, sx=sx, cx=cx, levels=levels, equations="Stokes-C", partitioner="Skew Cartesian").finalize()
+    O = cpu_oracle.Preconditioner(A, p, testvector=tv, nthreads=max(1, len(os.sched_getaffinity(0)))).compute()
+    assert O.flags == 0 and [s[1] for s in O.level_sizes()] == [s[1] for s in P.level_sizes()]
+    rng = np.random.default_rng(41)
+    for _ in range(2):
+        b = rng.uniform(-1, 1, A.shape[0])
+        assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-8
 
 
 @pytest.mark.gpu

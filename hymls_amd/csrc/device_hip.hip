@@ -1303,12 +1303,16 @@ __global__ void __launch_bounds__(256) k_lvl_bwd(const LvlTask* __restrict__ tas
 void solve_fwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
                      const double* x, double* y) {
   if (ntasks <= 0) return;
+  if ((size_t)lds_doubles * sizeof(double) > 64 * 1024)
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_lvl_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_doubles * sizeof(double))));
   hipLaunchKernelGGL(k_lvl_fwd, dim3(ntasks), dim3(256), (size_t)lds_doubles * sizeof(double), g_stream, tasks, subs, plans, x, y);
   launch_check();
 }
 void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
                      const double* y, double* x) {
   if (ntasks <= 0) return;
+  if ((size_t)lds_doubles * sizeof(double) > 64 * 1024)
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_lvl_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_doubles * sizeof(double))));
   hipLaunchKernelGGL(k_lvl_bwd, dim3(ntasks), dim3(256), (size_t)lds_doubles * sizeof(double), g_stream, tasks, subs, plans, y, x);
   launch_check();
 }

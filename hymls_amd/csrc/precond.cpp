@@ -215,6 +215,84 @@ int32_t BatchedLU::check_flag() const {
   return f;
 }
 
+// ------------------------------------------------------------------ merged level-synchronous solve tables
+// (device.hpp: solve_fwd_tasks / solve_bwd_tasks) for a set of (plan index, batch): one launch per tree level and sweep
+// covers every (class, member, front) of that level; a task is a whole small front or a 64-row tile of a large one
+bool merged_solve_fits(const ClassPlan& plan) {
+  for (auto& F : plan.fronts) if (F.w + F.ri > dev::LVL_MAX_ROWS) return false;
+  return true;
+}
+
+MergedSolve::~MergedSolve() { dev::free(d_subs); dev::free(d_fw); dev::free(d_bw); }
+
+void MergedSolve::build(const std::vector<std::pair<int32_t, const BatchedLU*>>& classes) {
+  dev::free(d_subs); dev::free(d_fw); dev::free(d_bw);
+  d_subs = nullptr; d_fw = d_bw = nullptr;
+  const int small_rows = std::getenv("HYMLS_MI_LVL_SMALL_ROWS") ? std::atoi(std::getenv("HYMLS_MI_LVL_SMALL_ROWS")) : dev::LVL_SMALL_ROWS;
+  std::vector<dev::LvlSub> lsubs;
+  std::vector<const ClassPlan*> sub_plan;
+  std::vector<std::vector<std::pair<int64_t, dev::LvlTask>>> fw, bw;   // per tree level: (cost, task)
+  for (auto& cb : classes) {
+    const BatchedLU& lu = *cb.second;
+    const size_t nl = lu.plan.levels.size();
+    if (fw.size() < nl) { fw.resize(nl); bw.resize(nl); }
+    for (size_t b = 0; b < lu.members.size(); b++) {
+      const int32_t sub = (int32_t)lsubs.size();
+      lsubs.push_back(dev::LvlSub{lu.batch.factor + (int64_t)b * lu.plan.factor_size,
+                                  lu.batch.contrib + (int64_t)b * lu.plan.contrib_size, lu.h_xoff[b], cb.first});
+      sub_plan.push_back(&lu.plan);
+      for (size_t l = 0; l < nl; l++) {
+        auto add = [&](int s) {
+          const Front& F = lu.plan.fronts[s];
+          const int rows = F.w + F.ri;
+          if (rows <= small_rows) {
+            fw[l].push_back({(int64_t)rows * F.w, dev::LvlTask{sub, s, -1, 0}});
+            bw[l].push_back({(int64_t)rows * F.w, dev::LvlTask{sub, s, -1, 0}});
+          } else {
+            for (int r0 = 0; r0 < rows; r0 += 64) fw[l].push_back({64LL * std::min(F.w, r0 + 63), dev::LvlTask{sub, s, r0, 0}});
+            for (int r0 = 0; r0 < F.w; r0 += 64) bw[l].push_back({64LL * (F.w - r0 + F.ri), dev::LvlTask{sub, s, r0, 0}});
+          }
+        };
+        for (int s : lu.plan.levels[l]) add(s);
+        for (int s : lu.plan.big_levels[l]) add(s);
+      }
+    }
+  }
+  nsubs = (int32_t)lsubs.size();
+  fw_off.assign(1, 0); bw_off.assign(1, 0); fw_lds.clear(); bw_lds.clear();
+  if (!nsubs) return;
+  std::vector<dev::LvlTask> tf, tb;
+  auto heavy_first = [](const std::pair<int64_t, dev::LvlTask>& a, const std::pair<int64_t, dev::LvlTask>& b) { return a.first > b.first; };
+  for (size_t l = 0; l < fw.size(); l++) {
+    std::stable_sort(fw[l].begin(), fw[l].end(), heavy_first);
+    std::stable_sort(bw[l].begin(), bw[l].end(), heavy_first);
+    int32_t lf = 0, lb = 0;
+    for (auto& t : fw[l]) {
+      const Front& F = sub_plan[t.second.sub]->fronts[t.second.front];
+      lf = std::max(lf, t.second.r0 < 0 ? F.w + F.ri : ((std::min(F.w, t.second.r0 + 63) + 7) & ~7) + 64 + 256);
+      tf.push_back(t.second);
+    }
+    for (auto& t : bw[l]) {
+      const Front& F = sub_plan[t.second.sub]->fronts[t.second.front];
+      lb = std::max(lb, t.second.r0 < 0 ? F.w + F.ri : ((F.w - t.second.r0 + F.ri + 7) & ~7) + 256);
+      tb.push_back(t.second);
+    }
+    fw_off.push_back((int32_t)tf.size()); bw_off.push_back((int32_t)tb.size());
+    fw_lds.push_back(lf); bw_lds.push_back(lb);
+  }
+  d_subs = dev::upload(lsubs);
+  d_fw = dev::upload(tf); d_bw = dev::upload(tb);
+}
+
+// x <- A^{-1} x for every member of every class of the tables; y: scratch of the same length
+void MergedSolve::solve(const dev::PlanD* d_plans, double* x, double* y) const {
+  const int nl = (int)fw_lds.size();
+  for (int l = 0; l < nl; l++)
+    dev::solve_fwd_tasks(d_fw + fw_off[l], fw_off[l + 1] - fw_off[l], d_subs, d_plans, fw_lds[l], x, y);
+  for (int l = nl - 1; l >= 0; l--)
+    dev::solve_bwd_tasks(d_bw + bw_off[l], bw_off[l + 1] - bw_off[l], d_subs, d_plans, bw_lds[l], y, x);
+}
+
 // ------------------------------------------------------------------ DirectSolver
 DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids, int64_t ngid,
                            const Params& cp, const ivec* clu_ptr, const ivec* clu, const ivec* clu_coord, bool border_pending) {
@@ -276,6 +354,14 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   HYMLS_CHECK(lu_->check_flag() == 0, -4, "coarse factorisation hit a zero or non-finite pivot");
   d_z_ = (double*)dev::alloc((size_t)n_ * sizeof(double));
   d_perm_ = dev::upload(lu_->plan.perm);
+  // the tree levels of one large system are launch-latency bound with one launch chain per level (assemble, panels,
+  // finalize, small fronts: about 100 launches per solve at 216 k unknowns); the merged task kernels need one launch
+  // per tree level and sweep
+  if (merged_solve_fits(lu_->plan) && !std::getenv("HYMLS_MI_NO_MERGED_SOLVE")) {
+    merged_.build({{0, lu_.get()}});
+    d_plan_ = dev::upload(std::vector<dev::PlanD>{lu_->dplan});
+    d_y_ = (double*)dev::alloc((size_t)n_ * sizeof(double));
+  }
   ivec fixpos;
   for (int lid : fix_lids_)
     if (lid > 0) fixpos.push_back(lu_->plan.iperm[lid]);  // CoarseSolver.cpp:288-289: lid 0 is not zeroed
@@ -285,6 +371,7 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
 
 DirectSolver::~DirectSolver() {
   dev::free(d_val_); dev::free(d_z_); dev::free(d_perm_); dev::free(d_fix_); dev::free(d_bZ_); dev::free(d_bW_);
+  dev::free(d_plan_); dev::free(d_y_);
 }
 
 void DirectSolver::solve(const double* b, double* x, bool zero_fixed) {
@@ -294,7 +381,8 @@ void DirectSolver::solve(const double* b, double* x, bool zero_fixed) {
     // zero the Dirichlet right-hand sides: scatter zeros
     dev::scatter((int64_t)fix_lids_.size(), d_fix_, dev::zeros16(), d_z_);
   }
-  lu_->solve(d_z_);
+  if (merged_.nsubs > 0) merged_.solve(d_plan_, d_z_, d_y_);
+  else lu_->solve(d_z_);
   dev::scatter(n_, d_perm_, d_z_, x);
 }
 
@@ -448,7 +536,7 @@ LevelSolver::~LevelSolver() {
     for (void* q : bp) dev::free(q);
     for (int32_t* q : d_orders_) dev::free(q); }
   dev::free(d_mv_row_); dev::free(d_mv_col_); dev::free(d_mv_src_); dev::free(d_mv_node_); dev::free(d_mv_val_); dev::free(d_mv_x_);
-  dev::free(d_lsubs_); dev::free(d_lfw_); dev::free(d_lbw_); dev::free(d_ytmp_);
+  dev::free(d_ytmp_);
   for (auto& b : blocks_) { dev::free(b.d_binv); dev::free(b.d_ids); dev::free(b.d_pull_ptr); dev::free(b.d_pull_base); }
 }
 
@@ -1242,67 +1330,19 @@ void LevelSolver::build_schur_setup() {
   // ---- merged level solve for the classes that do not fit (large subdomains of the coarser levels):
   // one launch per tree level and sweep for all of them together
   cls_merged_.assign(cls_.size(), 0);
-  const int small_rows = std::getenv("HYMLS_MI_LVL_SMALL_ROWS") ? std::atoi(std::getenv("HYMLS_MI_LVL_SMALL_ROWS")) : dev::LVL_SMALL_ROWS;
-  std::vector<dev::LvlSub> lsubs;
-  std::vector<std::vector<std::pair<int64_t, dev::LvlTask>>> fw, bw;   // per tree level: (cost, task)
+  std::vector<std::pair<int32_t, const BatchedLU*>> merged;
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
-    if (cls_fused_[c] || C.lu.plan.nI == 0 || std::getenv("HYMLS_MI_NO_MERGED_SOLVE")) continue;
-    bool ok = true;
-    for (auto& F : C.lu.plan.fronts) ok &= F.w + F.ri <= dev::LVL_MAX_ROWS;
-    if (!ok) continue;
+    if (cls_fused_[c] || C.lu.plan.nI == 0 || std::getenv("HYMLS_MI_NO_MERGED_SOLVE") || !merged_solve_fits(C.lu.plan)) continue;
     cls_merged_[c] = 1;
-    const size_t nl = C.lu.plan.levels.size();
-    if (fw.size() < nl) { fw.resize(nl); bw.resize(nl); }
-    for (size_t b = 0; b < C.lu.members.size(); b++) {
-      const int32_t sub = (int32_t)lsubs.size();
-      lsubs.push_back(dev::LvlSub{C.lu.batch.factor + (int64_t)b * C.lu.plan.factor_size,
-                                  C.lu.batch.contrib + (int64_t)b * C.lu.plan.contrib_size, C.lu.h_xoff[b], (int32_t)c});
-      for (size_t l = 0; l < nl; l++) {
-        auto add = [&](int s) {
-          const Front& F = C.lu.plan.fronts[s];
-          const int rows = F.w + F.ri;
-          if (rows <= small_rows) {
-            fw[l].push_back({(int64_t)rows * F.w, dev::LvlTask{sub, s, -1, 0}});
-            bw[l].push_back({(int64_t)rows * F.w, dev::LvlTask{sub, s, -1, 0}});
-          } else {
-            for (int r0 = 0; r0 < rows; r0 += 64) fw[l].push_back({64LL * std::min(F.w, r0 + 63), dev::LvlTask{sub, s, r0, 0}});
-            for (int r0 = 0; r0 < F.w; r0 += 64) bw[l].push_back({64LL * (F.w - r0 + F.ri), dev::LvlTask{sub, s, r0, 0}});
-          }
-        };
-        for (int s : C.lu.plan.levels[l]) add(s);
-        for (int s : C.lu.plan.big_levels[l]) add(s);
-      }
-    }
+    merged.emplace_back((int32_t)c, &C.lu);
   }
-  n_lsubs_ = (int32_t)lsubs.size();
-  lvl_fw_off_.assign(1, 0); lvl_bw_off_.assign(1, 0); lvl_fw_lds_.clear(); lvl_bw_lds_.clear();
-  if (n_lsubs_) {
-    std::vector<dev::LvlTask> tf, tb;
-    auto heavy_first = [](const std::pair<int64_t, dev::LvlTask>& a, const std::pair<int64_t, dev::LvlTask>& b) { return a.first > b.first; };
-    for (size_t l = 0; l < fw.size(); l++) {
-      std::stable_sort(fw[l].begin(), fw[l].end(), heavy_first);
-      std::stable_sort(bw[l].begin(), bw[l].end(), heavy_first);
-      int32_t lf = 0, lb = 0;
-      for (auto& t : fw[l]) {
-        const Front& F = cls_[lsubs[t.second.sub].cls]->lu.plan.fronts[t.second.front];
-        lf = std::max(lf, t.second.r0 < 0 ? F.w + F.ri : ((std::min(F.w, t.second.r0 + 63) + 7) & ~7) + 64 + 256);
-        tf.push_back(t.second);
-      }
-      for (auto& t : bw[l]) {
-        const Front& F = cls_[lsubs[t.second.sub].cls]->lu.plan.fronts[t.second.front];
-        lb = std::max(lb, t.second.r0 < 0 ? F.w + F.ri : ((F.w - t.second.r0 + F.ri + 7) & ~7) + 256);
-        tb.push_back(t.second);
-      }
-      lvl_fw_off_.push_back((int32_t)tf.size()); lvl_bw_off_.push_back((int32_t)tb.size());
-      lvl_fw_lds_.push_back(lf); lvl_bw_lds_.push_back(lb);
-    }
-    d_lsubs_ = dev::upload(lsubs);
-    d_lfw_ = dev::upload(tf); d_lbw_ = dev::upload(tb);
+  merged_.build(merged);
+  if (merged_.nsubs) {
     d_ytmp_ = (double*)dev::alloc((size_t)std::max(n1_, 1) * sizeof(double));
     if (std::getenv("HYMLS_MI_VERBOSE"))
-      std::fprintf(stderr, "[hymls_mi] rank %d level %d: merged level solve for %d subdomains, %zu tree levels, %zu + %zu tasks\n",
-                   comm_->rank, level_, n_lsubs_, fw.size(), tf.size(), tb.size());
+      std::fprintf(stderr, "[hymls_mi] rank %d level %d: merged level solve for %d subdomains, %zu tree levels\n",
+                   comm_->rank, level_, merged_.nsubs, merged_.fw_lds.size());
   }
 }
 
@@ -1531,13 +1571,7 @@ void LevelSolver::compute() {
 
 void LevelSolver::interior_solve(double* x1) {
   if (n_fsubs_ > 0) dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, x1);
-  if (n_lsubs_ > 0) {
-    const int nl = (int)lvl_fw_lds_.size();
-    for (int l = 0; l < nl; l++)
-      dev::solve_fwd_tasks(d_lfw_ + lvl_fw_off_[l], lvl_fw_off_[l + 1] - lvl_fw_off_[l], d_lsubs_, d_fplans_, lvl_fw_lds_[l], x1, d_ytmp_);
-    for (int l = nl - 1; l >= 0; l--)
-      dev::solve_bwd_tasks(d_lbw_ + lvl_bw_off_[l], lvl_bw_off_[l + 1] - lvl_bw_off_[l], d_lsubs_, d_fplans_, lvl_bw_lds_[l], d_ytmp_, x1);
-  }
+  if (merged_.nsubs > 0) merged_.solve(d_fplans_, x1, d_ytmp_);
   for (size_t c = 0; c < cls_.size(); c++)
     if (!cls_fused_[c] && !cls_merged_[c]) cls_[c]->lu.solve(x1);
 }
@@ -1578,7 +1612,7 @@ void LevelSolver::apply_inverse(const double* b, double* x) {
   // optional (HYMLS_MI_IO_FUSION=1; every subdomain in the fused kernel): the entry gather, y1 = A12 x2, x1 -= ... and
   // the exit scatter of the interior part ride on the load / store of the two interior solves.  Measured neutral at 256^3
   // (29.19 vs 29.35 ms: the scattered accesses cost the fused kernel what the separate kernels took), hence off by default.
-  const bool io_fused = n_fsubs_ > 0 && n_lsubs_ == 0 && (int64_t)n_fsubs_ == (int64_t)my_sds_.size() &&
+  const bool io_fused = n_fsubs_ > 0 && merged_.nsubs == 0 && (int64_t)n_fsubs_ == (int64_t)my_sds_.size() &&
                         std::getenv("HYMLS_MI_IO_FUSION") != nullptr;
   if (profiling) dev::mark(0, true);
   if (!io_fused) dev::gather(n1_, d_inperm_, b, z1);        // b1

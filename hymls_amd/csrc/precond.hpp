@@ -52,6 +52,22 @@ struct BatchedLU {
   int32_t check_flag() const;
 };
 
+// tables of the merged level-synchronous solve (device.hpp: solve_fwd_tasks / solve_bwd_tasks) for a set of batches
+struct MergedSolve {
+  dev::LvlSub* d_subs = nullptr;
+  dev::LvlTask *d_fw = nullptr, *d_bw = nullptr;
+  int32_t nsubs = 0;
+  ivec fw_off, bw_off, fw_lds, bw_lds;
+  MergedSolve() = default;
+  MergedSolve(const MergedSolve&) = delete;
+  MergedSolve& operator=(const MergedSolve&) = delete;
+  ~MergedSolve();
+  // (index of the batch's plan in the PlanD table handed to solve(), batch)
+  void build(const std::vector<std::pair<int32_t, const BatchedLU*>>& classes);
+  void solve(const dev::PlanD* d_plans, double* x, double* y) const;
+};
+bool merged_solve_fits(const ClassPlan& plan);   // every front within the LDS limits of the task kernels
+
 class Operator {  // something with ApplyInverse on device vectors in its own row ordering
  public:
   virtual ~Operator() {}
@@ -94,6 +110,9 @@ class DirectSolver : public Operator {
   dvec tail_col_, tail_row_;
   double tail_d_ = 0.0;
   std::unique_ptr<BatchedLU> lu_;
+  MergedSolve merged_;
+  dev::PlanD* d_plan_ = nullptr;
+  double* d_y_ = nullptr;
   double* d_val_ = nullptr;
   double* d_z_ = nullptr;
   int32_t* d_perm_ = nullptr;   // elimination position -> row
@@ -221,11 +240,8 @@ class LevelSolver : public Operator {
   std::vector<char> cls_fused_;
   // merged level solve tables (classes too large for the fused kernel)
   std::vector<char> cls_merged_;
-  dev::LvlSub* d_lsubs_ = nullptr;
-  dev::LvlTask *d_lfw_ = nullptr, *d_lbw_ = nullptr;
+  MergedSolve merged_;
   double* d_ytmp_ = nullptr;
-  int32_t n_lsubs_ = 0;
-  ivec lvl_fw_off_, lvl_bw_off_, lvl_fw_lds_, lvl_bw_lds_;
   // device
   double* d_kval_ = nullptr;
   int32_t *d_krow_ = nullptr, *d_kcol_ = nullptr;

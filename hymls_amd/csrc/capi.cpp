@@ -262,23 +262,26 @@ int hymls_mi_apply_inverse(hymls_mi_t* h, const double* B, int64_t ldb, double* 
   HYMLS_CHECK(h->computed, -1, "The preconditioner has not yet been computed.");
   const double t0 = now();
   const int64_t n = h->top->num_owned();
-  if (!on_device && h->buf_n < n) {
+  // several right-hand sides go through the multi-vector path in groups (the factors are streamed once per group)
+  const int group = std::max(1, std::min(nvec, 8));
+  if (!on_device && h->buf_n < n * group) {
     dev::free(h->d_b); dev::free(h->d_x);
-    h->d_b = (double*)dev::alloc(n * sizeof(double));
-    h->d_x = (double*)dev::alloc(n * sizeof(double));
-    h->buf_n = n;
+    h->d_b = (double*)dev::alloc(n * group * sizeof(double));
+    h->d_x = (double*)dev::alloc(n * group * sizeof(double));
+    h->buf_n = n * group;
   }
   const int bm = h->top->border_size();
   dvec tz(std::max(bm, 1), 0.0), s0(std::max(bm, 1), 0.0);
-  for (int k = 0; k < nvec; k++) {
+  for (int k = 0; k < nvec; k += group) {
+    const int g = std::min(group, nvec - k);
     if (on_device) {
-      if (bm) h->top->apply_inverse_bordered(B + k * ldb, tz.data(), X + k * ldx, s0.data());
-      else h->top->apply_inverse(B + k * ldb, X + k * ldx);
+      if (bm) for (int v = 0; v < g; v++) h->top->apply_inverse_bordered(B + (k + v) * ldb, tz.data(), X + (k + v) * ldx, s0.data());
+      else h->top->apply_inverse_mv(B + k * ldb, ldb, X + k * ldx, ldx, g);
     } else {
-      dev::h2d(h->d_b, B + k * ldb, n * sizeof(double));
-      if (bm) h->top->apply_inverse_bordered(h->d_b, tz.data(), h->d_x, s0.data());
-      else h->top->apply_inverse(h->d_b, h->d_x);
-      dev::d2h(X + k * ldx, h->d_x, n * sizeof(double));
+      for (int v = 0; v < g; v++) dev::h2d(h->d_b + v * n, B + (k + v) * ldb, n * sizeof(double));
+      if (bm) for (int v = 0; v < g; v++) h->top->apply_inverse_bordered(h->d_b + v * n, tz.data(), h->d_x + v * n, s0.data());
+      else h->top->apply_inverse_mv(h->d_b, n, h->d_x, n, g);
+      for (int v = 0; v < g; v++) dev::d2h(X + (k + v) * ldx, h->d_x + v * n, n * sizeof(double));
     }
   }
   h->n_apply++;

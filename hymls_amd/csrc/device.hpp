@@ -191,7 +191,8 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
 // level.  A task is one workgroup: a whole small front, or a 64-row tile of a large one (all its columns;
 // the assembly of the pivot entries it needs is fused in, which is why the forward sweep reads x and
 // writes y instead of working in place).
-struct LvlSub { const double* fac; double* contrib; int32_t xoff, cls; };   // one (class, member)
+struct LvlSub { const double* fac; double* contrib; int32_t xoff, cls; int64_t cstride; };   // one (class, member); cstride: distance of
+                                                                                             // the contribution vectors of two columns
 struct LvlTask { int32_t sub, front, r0, pad; };   // r0 < 0: whole front; else rows [r0, r0 + 64)
 constexpr int LVL_MAX_ROWS = 19000;                // w + ri limit of a front on this path (LDS vector: 152 KiB of the 160)
 constexpr int LVL_SMALL_ROWS = 256;                // fronts up to this many rows are one task
@@ -201,6 +202,17 @@ void solve_fwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, c
 // x[pivots] = U^{-1} y - (U^{-1} U12) x[ancestors]
 void solve_bwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
                      const double* y, double* x);
+
+// ---- several right-hand sides (column-major multivectors, leading dimension ld, nv columns): the factor panels are
+// streamed once for groups of up to 4 columns (the single-vector kernels with the per-row state replicated)
+constexpr int NV_MAX = 4;
+// lds_doubles: LDS need for one vector, front_doubles: the share of it that is not replicated per vector
+void interior_solve_fused_mv(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, int32_t front_doubles,
+                             double* x, int64_t ldx, int nv);
+void solve_fwd_tasks_mv(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
+                        const double* x, double* y, int64_t ld, int nv);
+void solve_bwd_tasks_mv(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
+                        const double* y, double* x, int64_t ld, int nv);
 
 // ---- separator-side kernels
 // Householder per owned group on a level separator vector: x <- 2 w (w.x) - x
@@ -230,6 +242,7 @@ void solve_transposed(const PlanD& P, const BatchD& B, const int32_t* order, int
 // all separator blocks of a level in one launch (blocks of any order; heavy ones first)
 struct BlkD { const double* binv; const int32_t* ids; int32_t nb, r0; };   // r0 < 0: all rows; else rows [r0, r0 + 64) (tiles of a large block)
 void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, double* y);
+void blocks_apply_all_mv(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, int64_t ldx, double* y, int64_t ldy, int nv);
 // in-place inverse (partial pivoting) of every block of the table, one launch
 void dense_invert_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, int32_t* flag);
 

@@ -1682,6 +1682,544 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
   launch_check();
 }
 
+// ------------------------------------------------------------------ multi-vector variants (several right-hand sides)
+// ApplyInverse with nvec > 1 (Epetra_MultiVector; the reference sizes its containers for numvec, src/HYMLS_MatrixBlock.cpp:
+// 335-344): the factor panels, the dominant bytes of a solve, are streamed ONCE for a group of NV columns -- every panel
+// entry loaded is used for NV multiply-adds.  Vectors are column-major with a leading dimension; the kernels are the
+// single-vector ones with the per-row state (accumulators, LDS vectors) replicated NV times.  A launcher picks the
+// widest group (4, 2, 1) whose LDS fits and walks over the columns.
+constexpr size_t LDS_LIMIT_BYTES = 160 * 1024;
+
+template <int NV>
+__global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
+                                                            double* __restrict__ x, int64_t ldx) {
+  extern __shared__ double lds[];
+  const FusedSub S = subs[blockIdx.x];
+  const PlanD P = plans[S.cls];
+  const int nI = P.nI, CS = P.contrib_size, FS = P.max_level_rows > 384 ? P.max_level_rows : 384;
+  double* X = lds;                       // [NV][nI]
+  double* C = X + NV * nI;               // [NV][CS]
+  double* Fv = C + NV * CS;              // [NV][FS]   (reduction scratch of the k-split levels inside, at +128)
+  FusedFront* LF = (FusedFront*)(Fv + NV * FS);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < P.nfronts; i += 256) {
+    const FrontD G = P.fronts[i];
+    FusedFront f;
+    f.c0 = G.c0; f.w = G.w; f.ri = G.ri; f.c_off = G.c_off; f.a_off = G.a_off; f.lf_off = G.lf_off; f.idx_off = G.idx_off; f.pad = 0;
+    f.lp_off = G.lp_off; f.q_off = G.q_off;
+    LF[i] = f;
+  }
+  double* xg = x + S.xoff;
+#pragma unroll
+  for (int v = 0; v < NV; v++)
+    for (int i = tid; i < nI; i += 256) X[v * nI + i] = xg[v * ldx + i];
+  __syncthreads();
+  const double* __restrict__ fac = S.fac;
+  // ---------------- forward
+  for (int lev = 0; lev < P.nlev; lev++) {
+    const int ib = P.fw_ptr[lev], ni = P.fw_ptr[lev + 1] - ib;
+    for (int it = tid; it < ni; it += 256) {
+      const FwRec rc = P.fw_rec[ib + it];
+      const int item = rc.item;
+      const FusedFront& F = LF[item >> 16];
+      const int r = item & 0xffff;
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        const double* Cv = C + v * CS;
+        double val = r < F.w ? X[v * nI + F.c0 + r] : 0.0;
+        if (rc.n != 0xffff) {
+#pragma unroll
+          for (int q = 0; q < 5; q++) if (q < rc.n) val += Cv[rc.s[q]];
+        } else {
+          for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) val += Cv[P.asm_src[t]];
+        }
+        if (r < F.w) Fv[v * FS + F.lf_off + r] = val; else C[v * CS + F.c_off + r - F.w] = val;
+      }
+    }
+    __syncthreads();
+    if (ni > 128) {
+      for (int it = tid; it < ni; it += 256) {
+        const int item = P.fw_items[ib + it];
+        const FusedFront& F = LF[item >> 16];
+        const int r = item & 0xffff, w = F.w;
+        int c1, tri;
+        const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
+        const double* f = Fv + F.lf_off;
+        const int kmax = r < w ? r : w;
+        double a[2][NV];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int v = 0; v < NV; v++) a[u][v] = 0.0;
+        int k = 0;
+        for (; k + 3 < kmax; k += 4) {
+          double l[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) l[u] = p[c1 * (k + u) - tri * (((k + u) * (k + u + 3)) >> 1)];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) a[u & 1][v] += l[u] * f[v * FS + k + u];
+        }
+        for (; k < kmax; k++) {
+          const double l = p[c1 * k - tri * ((k * (k + 3)) >> 1)];
+#pragma unroll
+          for (int v = 0; v < NV; v++) a[0][v] += l * f[v * FS + k];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const double sum = a[0][v] + a[1][v];
+          if (r < w) X[v * nI + F.c0 + r] = f[v * FS + r] + sum; else C[v * CS + F.c_off + r - w] -= sum;
+        }
+      }
+    } else {
+      const int RT = ni > 64 ? 128 : 64, KG = 256 / RT;
+      const int it = tid % RT, kg = tid / RT;
+      double a0[NV], a1[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) { a0[v] = 0.0; a1[v] = 0.0; }
+      if (it < ni) {
+        const int item = P.fw_items[ib + it];
+        const FusedFront& F = LF[item >> 16];
+        const int r = item & 0xffff, w = F.w;
+        int c1, tri;
+        const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
+        const double* f = Fv + F.lf_off;
+        const int kmax = r < w ? r : w;
+        auto at = [&](int kk) { return p[c1 * kk - tri * ((kk * (kk + 3)) >> 1)]; };
+        int k = kg;
+        for (; k + 3 * KG < kmax; k += 4 * KG) {
+          const double l0 = at(k), l1 = at(k + KG), l2 = at(k + 2 * KG), l3 = at(k + 3 * KG);
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            a0[v] += l0 * f[v * FS + k] + l2 * f[v * FS + k + 2 * KG];
+            a1[v] += l1 * f[v * FS + k + KG] + l3 * f[v * FS + k + 3 * KG];
+          }
+        }
+        for (; k < kmax; k += KG) {
+          const double l = at(k);
+#pragma unroll
+          for (int v = 0; v < NV; v++) a0[v] += l * f[v * FS + k];
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < NV; v++) Fv[v * FS + 128 + kg * RT + it] = a0[v] + a1[v];
+      __syncthreads();
+      if (tid < ni) {
+        const int item = P.fw_items[ib + tid];
+        const FusedFront& F = LF[item >> 16];
+        const int r = item & 0xffff;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          double sum = 0.0;
+          for (int g = 0; g < KG; g++) sum += Fv[v * FS + 128 + g * RT + tid];
+          if (r < F.w) X[v * nI + F.c0 + r] = Fv[v * FS + F.lf_off + r] + sum; else C[v * CS + F.c_off + r - F.w] -= sum;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---------------- backward
+  for (int lev = P.nlev - 1; lev >= 0; lev--) {
+    const int ib = P.bw_ptr[lev], ni = P.bw_ptr[lev + 1] - ib;
+    if (ni > 128) {
+      for (int it = tid; it < ni; it += 256) {
+        const int item = P.bw_items[ib + it];
+        const FusedFront& F = LF[item >> 16];
+        const int i = item & 0xffff, w = F.w, ri = F.ri;
+        int c1, tri;
+        const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
+        const double* Xs = X + F.c0;
+        double a[2][NV];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int v = 0; v < NV; v++) a[u][v] = 0.0;
+        int k = i;
+        for (; k + 3 < w; k += 4) {
+          double l[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) l[u] = p[c1 * (k + u) + tri * (((k + u) * (k + u + 1)) >> 1)];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) a[u & 1][v] += l[u] * Xs[v * nI + k + u];
+        }
+        for (; k < w; k++) {
+          const double l = p[c1 * k + tri * ((k * (k + 1)) >> 1)];
+#pragma unroll
+          for (int v = 0; v < NV; v++) a[0][v] += l * Xs[v * nI + k];
+        }
+        const double* __restrict__ qv = fac + F.q_off + i;
+        const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+        k = 0;
+        for (; k + 3 < ri; k += 4) {
+          double l[4]; int id[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { l[u] = qv[(int64_t)w * (k + u)]; id[u] = idx[k + u]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) a[u & 1][v] -= l[u] * X[v * nI + id[u]];
+        }
+        for (; k < ri; k++) {
+          const double l = qv[(int64_t)w * k]; const int id = idx[k];
+#pragma unroll
+          for (int v = 0; v < NV; v++) a[0][v] -= l * X[v * nI + id];
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) Fv[v * FS + it] = a[0][v] + a[1][v];
+      }
+      __syncthreads();
+      for (int it = tid; it < ni; it += 256) {
+        const int item = P.bw_items[ib + it];
+        const int dst = LF[item >> 16].c0 + (item & 0xffff);
+#pragma unroll
+        for (int v = 0; v < NV; v++) X[v * nI + dst] = Fv[v * FS + it];
+      }
+    } else {
+      const int RT = ni > 64 ? 128 : 64, KG = 256 / RT;
+      const int it = tid % RT, kg = tid / RT;
+      double a0[NV], a1[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) { a0[v] = 0.0; a1[v] = 0.0; }
+      if (it < ni) {
+        const int item = P.bw_items[ib + it];
+        const FusedFront& F = LF[item >> 16];
+        const int i = item & 0xffff, w = F.w, ri = F.ri;
+        int c1, tri;
+        const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
+        const double* Xs = X + F.c0;
+        auto at = [&](int kk) { return p[c1 * kk + tri * ((kk * (kk + 1)) >> 1)]; };
+        int k = i + kg;
+        for (; k + KG < w; k += 2 * KG) {
+          const double l0 = at(k), l1 = at(k + KG);
+#pragma unroll
+          for (int v = 0; v < NV; v++) { a0[v] += l0 * Xs[v * nI + k]; a1[v] += l1 * Xs[v * nI + k + KG]; }
+        }
+        for (; k < w; k += KG) {
+          const double l = at(k);
+#pragma unroll
+          for (int v = 0; v < NV; v++) a0[v] += l * Xs[v * nI + k];
+        }
+        const double* __restrict__ qv = fac + F.q_off + i;
+        const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+        k = kg;
+        for (; k + KG < ri; k += 2 * KG) {
+          const double q0 = qv[(int64_t)w * k], q1 = qv[(int64_t)w * (k + KG)];
+          const int i0 = idx[k], i1 = idx[k + KG];
+#pragma unroll
+          for (int v = 0; v < NV; v++) { a0[v] -= q0 * X[v * nI + i0]; a1[v] -= q1 * X[v * nI + i1]; }
+        }
+        for (; k < ri; k += KG) {
+          const double q0 = qv[(int64_t)w * k]; const int i0 = idx[k];
+#pragma unroll
+          for (int v = 0; v < NV; v++) a0[v] -= q0 * X[v * nI + i0];
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < NV; v++) Fv[v * FS + 128 + kg * RT + it] = a0[v] + a1[v];
+      __syncthreads();
+      if (tid < ni) {
+        const int item = P.bw_items[ib + tid];
+        const int dst = LF[item >> 16].c0 + (item & 0xffff);
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          double sum = 0.0;
+          for (int g = 0; g < KG; g++) sum += Fv[v * FS + 128 + g * RT + tid];
+          X[v * nI + dst] = sum;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++)
+    for (int i = tid; i < nI; i += 256) xg[v * ldx + i] = X[v * nI + i];
+}
+
+template <int NV>
+static void launch_fused_mv(int32_t nsub, const FusedSub* subs, const PlanD* plans, size_t shm, double* x, int64_t ldx) {
+  if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused_mv<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_interior_fused_mv<NV>, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, ldx);
+  launch_check();
+}
+// lds_doubles: LDS need of one vector; front_doubles: the part of it that holds the front descriptors (not replicated)
+void interior_solve_fused_mv(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, int32_t front_doubles,
+                             double* x, int64_t ldx, int nv) {
+  if (nsub <= 0 || nv <= 0) return;
+  const size_t per = (size_t)(lds_doubles - front_doubles) * sizeof(double), fixed = (size_t)front_doubles * sizeof(double);
+  int v = 0;
+  while (v < nv) {
+    int g = nv - v >= 4 ? 4 : (nv - v >= 2 ? 2 : 1);
+    while (g > 1 && per * g + fixed > LDS_LIMIT_BYTES) g >>= 1;
+    double* xv = x + (int64_t)v * ldx;
+    if (g == 4) launch_fused_mv<4>(nsub, subs, plans, per * 4 + fixed, xv, ldx);
+    else if (g == 2) launch_fused_mv<2>(nsub, subs, plans, per * 2 + fixed, xv, ldx);
+    else interior_solve_fused(nsub, subs, plans, lds_doubles, xv, nullptr);
+    v += g;
+  }
+}
+
+// merged level-synchronous solve, NV columns (k_lvl_fwd / k_lvl_bwd with the LDS vectors and accumulators replicated;
+// the contribution vectors of column v live cstride doubles behind those of column v - 1)
+template <int NV>
+__global__ void __launch_bounds__(256) k_lvl_fwd_mv(const LvlTask* __restrict__ tasks, const LvlSub* __restrict__ subs,
+                                                     const PlanD* __restrict__ plans, const double* __restrict__ x,
+                                                     double* __restrict__ y, int64_t ld, int32_t LS) {
+  extern __shared__ double f[];     // [NV][LS]
+  const LvlTask T = tasks[blockIdx.x];
+  const LvlSub S = subs[T.sub];
+  const PlanD* P = plans + S.cls;
+  const FrontD F = P->fronts[T.front];
+  const int tid = threadIdx.x, w = F.w, rows = F.w + F.ri;
+  const int64_t ldp = rows;
+  const double* xb = x + S.xoff;
+  double* yb = y + S.xoff;
+  double* cb = S.contrib;
+  const int64_t cs = S.cstride;
+  const int32_t* __restrict__ aptr = P->asm_ptr + F.a_off;
+  const int32_t* __restrict__ asrc = P->asm_src;
+  const double* __restrict__ Lp = S.fac + F.lp_off;
+  if (T.r0 < 0) {
+    for (int j = tid; j < rows; j += 256) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        double val = j < w ? xb[v * ld + F.c0 + j] : 0.0;
+        for (int t = aptr[j]; t < aptr[j + 1]; t++) val += cb[v * cs + asrc[t]];
+        f[v * LS + j] = val;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < rows; i += 256) {
+      const int kmax = i < w ? i : w;
+      double s0[NV], s1[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) { s0[v] = 0.0; s1[v] = 0.0; }
+      int k = 0;
+      for (; k + 1 < kmax; k += 2) {
+        const double l0 = Lp[i + ldp * k], l1 = Lp[i + ldp * (k + 1)];
+#pragma unroll
+        for (int v = 0; v < NV; v++) { s0[v] += l0 * f[v * LS + k]; s1[v] += l1 * f[v * LS + k + 1]; }
+      }
+      for (; k < kmax; k++) {
+        const double l0 = Lp[i + ldp * k];
+#pragma unroll
+        for (int v = 0; v < NV; v++) s0[v] += l0 * f[v * LS + k];
+      }
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        const double s = s0[v] + s1[v];
+        if (i < w) yb[v * ld + F.c0 + i] = f[v * LS + i] + s;
+        else cb[v * cs + F.c_off + i - w] = f[v * LS + i] - s;
+      }
+    }
+    return;
+  }
+  const int r0 = T.r0, lane = tid & 63, g = tid >> 6, i = r0 + lane;
+  const int kneed = min(w, r0 + 63);
+  const int KP = (kneed + 7) & ~7;
+  // per vector: [KP assembled pivots | 64 own rows | 4 x 64 reduction]
+  for (int j = tid; j < kneed; j += 256) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      double val = xb[v * ld + F.c0 + j];
+      for (int t = aptr[j]; t < aptr[j + 1]; t++) val += cb[v * cs + asrc[t]];
+      f[v * LS + j] = val;
+    }
+  }
+  if (tid < 64 && i < rows) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      double val = i < w ? xb[v * ld + F.c0 + i] : 0.0;
+      for (int t = aptr[i]; t < aptr[i + 1]; t++) val += cb[v * cs + asrc[t]];
+      f[v * LS + KP + lane] = val;
+    }
+  }
+  __syncthreads();
+  const int krow = i < rows ? (i < w ? i : w) : 0;
+  const double* __restrict__ Lr = Lp + (i < rows ? i : 0);
+  const int chunk = ((kneed + 31) / 32) * 8;
+  const int kb = g * chunk, ke = min(kb + chunk, kneed);
+  double acc[2][NV];
+#pragma unroll
+  for (int u = 0; u < 2; u++)
+#pragma unroll
+    for (int v = 0; v < NV; v++) acc[u][v] = 0.0;
+  int k = kb;
+  for (; k + 7 < ke; k += 8) {
+    double l[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) l[u] = (k + u < krow) ? Lr[ldp * (k + u)] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int v = 0; v < NV; v++) acc[u & 1][v] += l[u] * f[v * LS + k + u];
+  }
+  for (; k < ke; k++) if (k < krow) {
+    const double l = Lr[ldp * k];
+#pragma unroll
+    for (int v = 0; v < NV; v++) acc[0][v] += l * f[v * LS + k];
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++) f[v * LS + KP + 64 + g * 64 + lane] = acc[0][v] + acc[1][v];
+  __syncthreads();
+  if (g == 0 && i < rows) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const double* red = f + v * LS + KP + 64;
+      const double sum = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+      const double own = f[v * LS + KP + lane];
+      if (i < w) yb[v * ld + F.c0 + i] = own + sum;
+      else cb[v * cs + F.c_off + i - w] = own - sum;
+    }
+  }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) k_lvl_bwd_mv(const LvlTask* __restrict__ tasks, const LvlSub* __restrict__ subs,
+                                                     const PlanD* __restrict__ plans, const double* __restrict__ y,
+                                                     double* __restrict__ x, int64_t ld, int32_t LS) {
+  extern __shared__ double f[];
+  const LvlTask T = tasks[blockIdx.x];
+  const LvlSub S = subs[T.sub];
+  const PlanD* P = plans + S.cls;
+  const FrontD F = P->fronts[T.front];
+  const int tid = threadIdx.x, w = F.w, ri = F.ri;
+  const int64_t ldp = w + ri;
+  double* xb = x + S.xoff;
+  const double* yb = y + S.xoff;
+  const int32_t* __restrict__ idx = P->fidx + F.idx_off + w;
+  const double* __restrict__ Lp = S.fac + F.lp_off;
+  const double* __restrict__ Q = S.fac + F.q_off;
+  if (T.r0 < 0) {
+    for (int k = tid; k < w + ri; k += 256) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) f[v * LS + k] = k < w ? yb[v * ld + F.c0 + k] : xb[v * ld + idx[k - w]];
+    }
+    __syncthreads();
+    for (int i = tid; i < w; i += 256) {
+      double s[NV], t[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) { s[v] = 0.0; t[v] = 0.0; }
+      for (int k = i; k < w; k++) {
+        const double l = Lp[i + ldp * k];
+#pragma unroll
+        for (int v = 0; v < NV; v++) s[v] += l * f[v * LS + k];
+      }
+      for (int k = 0; k < ri; k++) {
+        const double q = Q[i + (int64_t)w * k];
+#pragma unroll
+        for (int v = 0; v < NV; v++) t[v] += q * f[v * LS + w + k];
+      }
+#pragma unroll
+      for (int v = 0; v < NV; v++) xb[v * ld + F.c0 + i] = s[v] - t[v];
+    }
+    return;
+  }
+  const int r0 = T.r0, lane = tid & 63, g = tid >> 6, i = r0 + lane;
+  const int nU = w - r0, total = nU + ri;
+  const int TP = (total + 7) & ~7;
+  for (int k = tid; k < total; k += 256) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) f[v * LS + k] = k < nU ? yb[v * ld + F.c0 + r0 + k] : xb[v * ld + idx[k - nU]];
+  }
+  __syncthreads();
+  const int iv = i < w ? i : r0;
+  const double* __restrict__ Lr = Lp + iv + ldp * r0;
+  const double* __restrict__ Qr = Q + iv;
+  const int chunk = ((total + 31) / 32) * 8;
+  const int kb = g * chunk, ke = min(kb + chunk, total);
+  double acc[2][NV];
+#pragma unroll
+  for (int u = 0; u < 2; u++)
+#pragma unroll
+    for (int v = 0; v < NV; v++) acc[u][v] = 0.0;
+  {
+    const int e = min(ke, nU);
+    int k = kb;
+    for (; k + 7 < e; k += 8) {
+      double l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) l[u] = (k + u >= lane) ? Lr[ldp * (k + u)] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) acc[u & 1][v] += l[u] * f[v * LS + k + u];
+    }
+    for (; k < e; k++) if (k >= lane) {
+      const double l = Lr[ldp * k];
+#pragma unroll
+      for (int v = 0; v < NV; v++) acc[0][v] += l * f[v * LS + k];
+    }
+  }
+  {
+    int k = max(kb, nU);
+    for (; k + 7 < ke; k += 8) {
+      double l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) l[u] = Qr[(int64_t)w * (k - nU + u)];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) acc[u & 1][v] -= l[u] * f[v * LS + k + u];
+    }
+    for (; k < ke; k++) {
+      const double l = Qr[(int64_t)w * (k - nU)];
+#pragma unroll
+      for (int v = 0; v < NV; v++) acc[0][v] -= l * f[v * LS + k];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++) f[v * LS + TP + g * 64 + lane] = acc[0][v] + acc[1][v];
+  __syncthreads();
+  if (g == 0 && i < w) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const double* red = f + v * LS + TP;
+      xb[v * ld + F.c0 + i] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+    }
+  }
+}
+
+template <int NV>
+static void launch_lvl_mv(bool fwd, const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t ls,
+                          const double* a, double* b, int64_t ld) {
+  const size_t shm = (size_t)ls * NV * sizeof(double);
+  if (fwd) {
+    if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_lvl_fwd_mv<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(k_lvl_fwd_mv<NV>, dim3(ntasks), dim3(256), shm, g_stream, tasks, subs, plans, a, b, ld, ls);
+  } else {
+    if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_lvl_bwd_mv<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(k_lvl_bwd_mv<NV>, dim3(ntasks), dim3(256), shm, g_stream, tasks, subs, plans, a, b, ld, ls);
+  }
+  launch_check();
+}
+static void lvl_tasks_mv(bool fwd, const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
+                         const double* a, double* b, int64_t ld, int nv) {
+  if (ntasks <= 0 || nv <= 0) return;
+  int v = 0;
+  while (v < nv) {
+    int g = nv - v >= 4 ? 4 : (nv - v >= 2 ? 2 : 1);
+    while (g > 1 && (size_t)lds_doubles * g * sizeof(double) > LDS_LIMIT_BYTES) g >>= 1;
+    const double* av = a + (int64_t)v * ld;
+    double* bv = b + (int64_t)v * ld;
+    if (g == 4) launch_lvl_mv<4>(fwd, tasks, ntasks, subs, plans, lds_doubles, av, bv, ld);
+    else if (g == 2) launch_lvl_mv<2>(fwd, tasks, ntasks, subs, plans, lds_doubles, av, bv, ld);
+    else if (fwd) solve_fwd_tasks(tasks, ntasks, subs, plans, lds_doubles, av, bv);
+    else solve_bwd_tasks(tasks, ntasks, subs, plans, lds_doubles, av, bv);
+    v += g;
+  }
+}
+void solve_fwd_tasks_mv(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
+                        const double* x, double* y, int64_t ld, int nv) {
+  lvl_tasks_mv(true, tasks, ntasks, subs, plans, lds_doubles, x, y, ld, nv);
+}
+void solve_bwd_tasks_mv(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,
+                        const double* y, double* x, int64_t ld, int nv) {
+  lvl_tasks_mv(false, tasks, ntasks, subs, plans, lds_doubles, y, x, ld, nv);
+}
+
 // ------------------------------------------------------------------ separator-side kernels
 // eight lanes per group (the groups have 8 nodes on average; consecutive groups are contiguous, so a wave still
 // reads one contiguous stretch): dot product by shuffle reduction inside the 8 lanes, then the axpy
@@ -1924,6 +2462,62 @@ void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* i
   const int bs = nb <= 64 ? 64 : (nb <= 128 ? 128 : 256);
   hipLaunchKernelGGL(k_blocks_apply, dim3(nblk), dim3(bs), (size_t)nb * sizeof(double), g_stream, nb, binv, ids, x, y);
   launch_check();
+}
+
+template <int NV>
+__global__ void __launch_bounds__(64) k_blocks_apply_all_mv(const BlkD* __restrict__ blocks, const double* __restrict__ x, int64_t ldx,
+                                                             double* __restrict__ y, int64_t ldy, int32_t XS) {
+  extern __shared__ double xs[];   // [NV][XS]
+  const BlkD D = blocks[blockIdx.x];
+  const int nb = D.nb;
+  for (int j = threadIdx.x; j < nb; j += 64) {
+    const int id = D.ids[j];
+#pragma unroll
+    for (int v = 0; v < NV; v++) xs[v * XS + j] = x[v * ldx + id];
+  }
+  __syncthreads();
+  const int i0 = D.r0 < 0 ? 0 : D.r0, i1 = D.r0 < 0 ? nb : min(nb, D.r0 + 64);
+  for (int i = i0 + threadIdx.x; i < i1; i += 64) {
+    const double* __restrict__ M = D.binv + i;
+    double a[2][NV];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int v = 0; v < NV; v++) a[u][v] = 0.0;
+    int j = 0;
+    for (; j + 7 < nb; j += 8) {
+      double l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) l[u] = M[(int64_t)nb * (j + u)];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int v = 0; v < NV; v++) a[u & 1][v] += l[u] * xs[v * XS + j + u];
+    }
+    for (; j < nb; j++) {
+      const double l = M[(int64_t)nb * j];
+#pragma unroll
+      for (int v = 0; v < NV; v++) a[0][v] += l * xs[v * XS + j];
+    }
+    const int id = D.ids[i];
+#pragma unroll
+    for (int v = 0; v < NV; v++) y[v * ldy + id] = a[0][v] + a[1][v];
+  }
+}
+void blocks_apply_all_mv(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, int64_t ldx, double* y, int64_t ldy, int nv) {
+  if (nblk <= 0 || nv <= 0) return;
+  int v = 0;
+  while (v < nv) {
+    int g = nv - v >= 4 ? 4 : (nv - v >= 2 ? 2 : 1);
+    while (g > 1 && (size_t)max_nb * g * sizeof(double) > 64 * 1024) g >>= 1;
+    const double* xv = x + (int64_t)v * ldx;
+    double* yv = y + (int64_t)v * ldy;
+    const size_t shm = (size_t)max_nb * g * sizeof(double);
+    if (g == 4) { hipLaunchKernelGGL(k_blocks_apply_all_mv<4>, dim3(nblk), dim3(64), shm, g_stream, blocks, xv, ldx, yv, ldy, max_nb); launch_check(); }
+    else if (g == 2) { hipLaunchKernelGGL(k_blocks_apply_all_mv<2>, dim3(nblk), dim3(64), shm, g_stream, blocks, xv, ldx, yv, ldy, max_nb); launch_check(); }
+    else blocks_apply_all(nblk, blocks, max_nb, xv, yv);
+    v += g;
+  }
 }
 
 }  // namespace dev

@@ -134,7 +134,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   scratch_need_ = std::max<int64_t>(1, (int64_t)chunk * plan.scratch_size);
   sblock_need_ = with_sblock ? std::max<int64_t>(1, (int64_t)chunk * plan.nS * plan.nS) : 0;
   batch.scratch = nullptr; batch.sblock = nullptr;
-  batch.contrib = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)nb * plan.contrib_size) * sizeof(double)));
+  batch.contrib = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)contrib_nv * nb * plan.contrib_size) * sizeof(double)));
   batch.flag = (int32_t*)keep(dev::alloc(sizeof(int32_t)));
   dev::zero(batch.flag, sizeof(int32_t));
   h_fronts = fd;
@@ -231,6 +231,7 @@ void MergedSolve::build(const std::vector<std::pair<int32_t, const BatchedLU*>>&
   const int small_rows = std::getenv("HYMLS_MI_LVL_SMALL_ROWS") ? std::atoi(std::getenv("HYMLS_MI_LVL_SMALL_ROWS")) : dev::LVL_SMALL_ROWS;
   std::vector<dev::LvlSub> lsubs;
   std::vector<const ClassPlan*> sub_plan;
+  max_nv = dev::NV_MAX;
   std::vector<std::vector<std::pair<int64_t, dev::LvlTask>>> fw, bw;   // per tree level: (cost, task)
   for (auto& cb : classes) {
     const BatchedLU& lu = *cb.second;
@@ -239,7 +240,9 @@ void MergedSolve::build(const std::vector<std::pair<int32_t, const BatchedLU*>>&
     for (size_t b = 0; b < lu.members.size(); b++) {
       const int32_t sub = (int32_t)lsubs.size();
       lsubs.push_back(dev::LvlSub{lu.batch.factor + (int64_t)b * lu.plan.factor_size,
-                                  lu.batch.contrib + (int64_t)b * lu.plan.contrib_size, lu.h_xoff[b], cb.first});
+                                  lu.batch.contrib + (int64_t)b * lu.plan.contrib_size, lu.h_xoff[b], cb.first,
+                                  (int64_t)lu.members.size() * lu.plan.contrib_size});
+      max_nv = std::min(max_nv, lu.contrib_nv);
       sub_plan.push_back(&lu.plan);
       for (size_t l = 0; l < nl; l++) {
         auto add = [&](int s) {
@@ -284,13 +287,18 @@ void MergedSolve::build(const std::vector<std::pair<int32_t, const BatchedLU*>>&
   d_fw = dev::upload(tf); d_bw = dev::upload(tb);
 }
 
-// x <- A^{-1} x for every member of every class of the tables; y: scratch of the same length
-void MergedSolve::solve(const dev::PlanD* d_plans, double* x, double* y) const {
+// x <- A^{-1} x for every member of every class of the tables, nv columns with leading dimension ld; y: scratch (same shape)
+void MergedSolve::solve(const dev::PlanD* d_plans, double* x, double* y, int64_t ld, int nv) const {
   const int nl = (int)fw_lds.size();
-  for (int l = 0; l < nl; l++)
-    dev::solve_fwd_tasks(d_fw + fw_off[l], fw_off[l + 1] - fw_off[l], d_subs, d_plans, fw_lds[l], x, y);
-  for (int l = nl - 1; l >= 0; l--)
-    dev::solve_bwd_tasks(d_bw + bw_off[l], bw_off[l + 1] - bw_off[l], d_subs, d_plans, bw_lds[l], y, x);
+  for (int v0 = 0; v0 < nv; v0 += max_nv) {   // (column groups no wider than the contribution scratch of the batches)
+    const int g = std::min(max_nv, nv - v0);
+    double* xv = x + (int64_t)v0 * ld;
+    double* yv = y + (int64_t)v0 * ld;
+    for (int l = 0; l < nl; l++)
+      dev::solve_fwd_tasks_mv(d_fw + fw_off[l], fw_off[l + 1] - fw_off[l], d_subs, d_plans, fw_lds[l], xv, yv, ld, g);
+    for (int l = nl - 1; l >= 0; l--)
+      dev::solve_bwd_tasks_mv(d_bw + bw_off[l], bw_off[l + 1] - bw_off[l], d_subs, d_plans, bw_lds[l], yv, xv, ld, g);
+  }
 }
 
 // ------------------------------------------------------------------ DirectSolver
@@ -345,6 +353,7 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   if (std::getenv("HYMLS_MI_VERBOSE")) print_plan_stats(lu_->plan, "coarse solver", 1);
   lu_->members = {0};
   lu_->h_xoff = {0};
+  lu_->contrib_nv = dev::NV_MAX;
   // entry e of the extended CSR is entry e of A
   lu_->h_src.resize(A.col.size());
   std::iota(lu_->h_src.begin(), lu_->h_src.end(), 0);
@@ -352,7 +361,6 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   d_val_ = dev::upload(A.val);
   lu_->factor_chunk(d_val_, 0, 1);
   HYMLS_CHECK(lu_->check_flag() == 0, -4, "coarse factorisation hit a zero or non-finite pivot");
-  d_z_ = (double*)dev::alloc((size_t)n_ * sizeof(double));
   d_perm_ = dev::upload(lu_->plan.perm);
   // the tree levels of one large system are launch-latency bound with one launch chain per level (assemble, panels,
   // finalize, small fronts: about 100 launches per solve at 216 k unknowns); the merged task kernels need one launch
@@ -360,7 +368,6 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   if (merged_solve_fits(lu_->plan) && !std::getenv("HYMLS_MI_NO_MERGED_SOLVE")) {
     merged_.build({{0, lu_.get()}});
     d_plan_ = dev::upload(std::vector<dev::PlanD>{lu_->dplan});
-    d_y_ = (double*)dev::alloc((size_t)n_ * sizeof(double));
   }
   ivec fixpos;
   for (int lid : fix_lids_)
@@ -374,19 +381,29 @@ DirectSolver::~DirectSolver() {
   dev::free(d_plan_); dev::free(d_y_);
 }
 
-void DirectSolver::solve(const double* b, double* x, bool zero_fixed) {
+void DirectSolver::solve(const double* b, double* x, bool zero_fixed) { solve_mv(b, n_, x, n_, 1, zero_fixed); }
+
+void DirectSolver::solve_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv, bool zero_fixed) {
   if (n_ == 0) return;
-  dev::gather(n_, d_perm_, b, d_z_);
-  if (zero_fixed && !fix_lids_.empty()) {
-    // zero the Dirichlet right-hand sides: scatter zeros
-    dev::scatter((int64_t)fix_lids_.size(), d_fix_, dev::zeros16(), d_z_);
+  if (nv > nv_alloc_) {
+    dev::sync();
+    dev::free(d_z_); dev::free(d_y_);
+    d_z_ = (double*)dev::alloc((size_t)n_ * nv * sizeof(double));
+    d_y_ = merged_.nsubs > 0 ? (double*)dev::alloc((size_t)n_ * nv * sizeof(double)) : nullptr;
+    nv_alloc_ = nv;
   }
-  if (merged_.nsubs > 0) merged_.solve(d_plan_, d_z_, d_y_);
-  else lu_->solve(d_z_);
-  dev::scatter(n_, d_perm_, d_z_, x);
+  for (int v = 0; v < nv; v++) {
+    dev::gather(n_, d_perm_, b + v * ldb, d_z_ + (size_t)v * n_);
+    if (zero_fixed && !fix_lids_.empty())   // zero the Dirichlet right-hand sides: scatter zeros
+      dev::scatter((int64_t)fix_lids_.size(), d_fix_, dev::zeros16(), d_z_ + (size_t)v * n_);
+  }
+  if (merged_.nsubs > 0) merged_.solve(d_plan_, d_z_, d_y_, n_, nv);
+  else for (int v = 0; v < nv; v++) lu_->solve(d_z_ + (size_t)v * n_);
+  for (int v = 0; v < nv; v++) dev::scatter(n_, d_perm_, d_z_ + (size_t)v * n_, x + v * ldx);
 }
 
 void DirectSolver::apply_inverse(const double* b, double* x) { solve(b, x, true); }
+void DirectSolver::apply_inverse_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv) { solve_mv(b, ldb, x, ldx, nv, true); }
 
 // CoarseSolver with a border (reference src/HYMLS_CoarseSolver.cpp:196-260,454-560): the reference factors the
 // AugmentedMatrix [A V; W' C]; here A (with its Dirichlet fixes) is already factored, so the same solution is
@@ -1302,7 +1319,7 @@ void LevelSolver::build_schur_setup() {
   std::vector<dev::PlanD> plans;
   std::vector<dev::FusedSub> subs;
   cls_fused_.assign(cls_.size(), 0);
-  fused_lds_ = 0;
+  fused_lds_ = 0; fused_front_lds_ = 0; fused_vec_lds_ = 0;
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
     const int32_t need = C.lu.plan.nI + C.lu.plan.contrib_size + std::max(C.lu.plan.max_level_rows, 384) +
@@ -1312,11 +1329,14 @@ void LevelSolver::build_schur_setup() {
     const bool fused = !(any_big || C.lu.plan.max_level_rows > dev::FUSED_MAX_ITEMS || need > LDS_CAP || C.lu.plan.nI == 0 ||
                          C.lu.plan.fw_items.empty() || std::getenv("HYMLS_MI_NO_FUSED_SOLVE"));
     C.lu.packed = fused && !std::getenv("HYMLS_MI_NO_PACKED_PANELS");
+    C.lu.contrib_nv = fused ? 1 : dev::NV_MAX;   // (the fused kernel keeps its contribution vectors in LDS)
     C.lu.upload(SCRATCH_BUDGET, true);
     plans.push_back(C.lu.dplan);
     if (!fused) continue;
     cls_fused_[c] = 1;
     fused_lds_ = std::max(fused_lds_, need);
+    fused_front_lds_ = std::max(fused_front_lds_, (int32_t)(C.lu.plan.fronts.size() * 6 + 1));
+    fused_vec_lds_ = std::max(fused_vec_lds_, need - (int32_t)(C.lu.plan.fronts.size() * 6 + 1));
     for (size_t b = 0; b < C.lu.members.size(); b++)
       subs.push_back(dev::FusedSub{C.lu.batch.factor + (int64_t)b * C.lu.plan.factor_size, C.lu.h_xoff[b], (int32_t)c});
   }
@@ -1339,7 +1359,7 @@ void LevelSolver::build_schur_setup() {
   }
   merged_.build(merged);
   if (merged_.nsubs) {
-    d_ytmp_ = (double*)dev::alloc((size_t)std::max(n1_, 1) * sizeof(double));
+    d_ytmp_ = (double*)dev::alloc((size_t)std::max(n1_ + ngi_ + n2_, 1) * sizeof(double));
     if (std::getenv("HYMLS_MI_VERBOSE"))
       std::fprintf(stderr, "[hymls_mi] rank %d level %d: merged level solve for %d subdomains, %zu tree levels\n",
                    comm_->rank, level_, merged_.nsubs, merged_.fw_lds.size());
@@ -1437,8 +1457,8 @@ void LevelSolver::build_handoff(const ivec& next_owned) {
   xch_down_.build(*comm_, want, dst, [nown](int64_t k) { return k < nown ? (int32_t)k : -1; });
   dev::free(d_nrhs_); dev::free(d_nsol_);
   n_next_owned_ = (int64_t)next_owned.size();
-  d_nrhs_ = (double*)dev::alloc(std::max<size_t>(1, next_owned.size()) * sizeof(double));
-  d_nsol_ = (double*)dev::alloc(std::max<size_t>(1, next_owned.size()) * sizeof(double));
+  d_nrhs_ = (double*)dev::alloc(std::max<size_t>(1, next_owned.size()) * nvec_alloc_ * sizeof(double));
+  d_nsol_ = (double*)dev::alloc(std::max<size_t>(1, next_owned.size()) * nvec_alloc_ * sizeof(double));
 }
 
 void LevelSolver::compute() {
@@ -1569,83 +1589,111 @@ void LevelSolver::compute() {
   }
 }
 
-void LevelSolver::interior_solve(double* x1) {
-  if (n_fsubs_ > 0) dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, x1);
-  if (merged_.nsubs > 0) merged_.solve(d_fplans_, x1, d_ytmp_);
+void LevelSolver::interior_solve(double* x1) { interior_solve_mv(x1, n1_ + ngi_, 1); }
+
+// x1 <- A11^{-1} x1 for nv columns (leading dimension ld): the factor panels are streamed once per group of columns
+void LevelSolver::interior_solve_mv(double* x1, int64_t ld, int nv) {
+  if (n_fsubs_ > 0) {
+    if (nv == 1) dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, x1);
+    else dev::interior_solve_fused_mv(n_fsubs_, d_fsubs_, d_fplans_, fused_vec_lds_ + fused_front_lds_, fused_front_lds_, x1, ld, nv);
+  }
+  if (merged_.nsubs > 0) {
+    ensure_nvec(nv);   // (the scratch shares the leading dimension of x: ld <= n1 + ngi + n2)
+    merged_.solve(d_fplans_, x1, d_ytmp_, ld, nv);
+  }
   for (size_t c = 0; c < cls_.size(); c++)
-    if (!cls_fused_[c] && !cls_merged_[c]) cls_[c]->lu.solve(x1);
+    if (!cls_fused_[c] && !cls_merged_[c])
+      for (int v = 0; v < nv; v++) cls_[c]->lu.solve(x1 + v * ld);
+}
+
+// buffers of the apply for nv right-hand sides (column-major, every vector with the single-vector layout)
+void LevelSolver::ensure_nvec(int nv) {
+  if (nv <= nvec_alloc_) return;
+  dev::sync();
+  auto grow = [&](double*& p, int64_t len) { dev::free(p); p = (double*)dev::alloc((size_t)std::max<int64_t>(len, 1) * nv * sizeof(double)); };
+  grow(d_z_, n1_ + ngi_ + n2_); grow(d_t1_, n1_); grow(d_t2_, n2_ + ngs_);
+  if (!direct_schur_) { const int64_t ng = (int64_t)vs_.size(); grow(d_vrhs_, ng); grow(d_vsol_, ng); }
+  if (d_nrhs_) { grow(d_nrhs_, n_next_owned_); grow(d_nsol_, n_next_owned_); }
+  if (d_ytmp_) grow(d_ytmp_, n1_ + ngi_ + n2_);
+  nvec_alloc_ = nv;
 }
 
 // rhs/sol: entries of the nodes this rank owns on this level that go on to the next one
-void LevelSolver::next_apply(const double* rhs, double* sol) {
-  if (!comm_->distributed()) { next_->apply_inverse(rhs, sol); return; }
-  xch_down_.forward(rhs, d_nrhs_);
-  next_->apply_inverse(d_nrhs_, d_nsol_);
-  if (next_is_direct_) {
-    // every rank solved the whole coarse system: keep the entries owned here (rows are in rank order)
-    if (red_.n) dev::d2d(sol, d_nsol_ + glob_row_off_[comm_->rank], (size_t)red_.n * sizeof(double));
-  } else {
-    xch_down_.backward(d_nsol_, sol);
+void LevelSolver::next_apply(const double* rhs, double* sol, int64_t ld, int nv) {
+  if (!comm_->distributed()) { next_->apply_inverse_mv(rhs, ld, sol, ld, nv); return; }
+  const int64_t ldn = std::max<int64_t>(n_next_owned_, 1);
+  for (int v = 0; v < nv; v++) xch_down_.forward(rhs + v * ld, d_nrhs_ + v * ldn);
+  next_->apply_inverse_mv(d_nrhs_, ldn, d_nsol_, ldn, nv);
+  for (int v = 0; v < nv; v++) {
+    if (next_is_direct_) {
+      // every rank solved the whole coarse system: keep the entries owned here (rows are in rank order)
+      if (red_.n) dev::d2d(sol + v * ld, d_nsol_ + v * ldn + glob_row_off_[comm_->rank], (size_t)red_.n * sizeof(double));
+    } else {
+      xch_down_.backward(d_nsol_ + v * ldn, sol + v * ld);
+    }
   }
 }
 
-void LevelSolver::schur_apply(double* rhs2, double* x2) {
+void LevelSolver::schur_apply(double* rhs2, int64_t ldr, double* x2, int64_t ldx, int nv) {
   if (global_n2_ == 0) return;
-  if (direct_schur_) { next_apply(rhs2, x2); return; }
+  if (direct_schur_) {
+    // (the direct solver of the whole Schur complement takes any leading dimensions)
+    if (!comm_->distributed()) { next_->apply_inverse_mv(rhs2, ldr, x2, ldx, nv); return; }
+    for (int v = 0; v < nv; v++) next_apply(rhs2 + v * ldr, x2 + v * ldx, 0, 1);
+    return;
+  }
   // SchurPreconditioner::ApplyInverse (reference src/HYMLS_SchurPreconditioner.cpp:1010-1093)
   const int ng = (int)vs_.size();
-  dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);                       // B' = H rhs
-  dev::blocks_apply_all(n_blk_apply_, d_blka_, blk_max_nb_, rhs2, x2);
-  dev::gather(ng, d_vs_, rhs2, d_vrhs_);
+  const int64_t ldv = std::max(ng, 1);
+  for (int v = 0; v < nv; v++) dev::ot_apply(ng, d_gptr_, d_otw_, rhs2 + v * ldr);                   // B' = H rhs
+  dev::blocks_apply_all_mv(n_blk_apply_, d_blka_, blk_max_nb_, rhs2, ldr, x2, ldx, nv);
+  for (int v = 0; v < nv; v++) dev::gather(ng, d_vs_, rhs2 + v * ldr, d_vrhs_ + v * ldv);
   if (profiling && level_ == 0) dev::mark(4, true);
-  next_apply(d_vrhs_, d_vsol_);
+  next_apply(d_vrhs_, d_vsol_, ldv, nv);
   if (profiling && level_ == 0) dev::mark(4, false);
-  dev::scatter(ng, d_vs_, d_vsol_, x2);
-  dev::ot_apply(ng, d_gptr_, d_otw_, x2);                         // Y = H Y
+  for (int v = 0; v < nv; v++) {
+    dev::scatter(ng, d_vs_, d_vsol_ + v * ldv, x2 + v * ldx);
+    dev::ot_apply(ng, d_gptr_, d_otw_, x2 + v * ldx);                                              // Y = H Y
+  }
 }
 
-void LevelSolver::apply_inverse(const double* b, double* x) {
+void LevelSolver::apply_inverse(const double* b, double* x) { apply_inverse_mv(b, 0, x, 0, 1); }
+
+// Preconditioner::ApplyInverse (reference src/HYMLS_Preconditioner.cpp:930-1070) for nv right-hand sides; the two
+// interior solves, the separator blocks and the coarser levels read their factors once per group of up to NV_MAX columns
+void LevelSolver::apply_inverse_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv) {
   HYMLS_CHECK(next_ != nullptr || global_n2_ == 0, -1, "The preconditioner has not yet been computed.");
-  // Preconditioner::ApplyInverse (reference src/HYMLS_Preconditioner.cpp:930-1070)
-  double* z1 = d_z_;                    // [x1 | x1 of the neighbours next to my separators | x2]
+  ensure_nvec(nv);
+  const int64_t ldz = n1_ + ngi_ + n2_, ld1 = std::max(n1_, 1), ld2 = std::max(n2_ + ngs_, 1);
+  double* z1 = d_z_;                    // per column: [x1 | x1 of the neighbours next to my separators | x2]
   double* z2 = d_z_ + n1_ + ngi_;
-  // optional (HYMLS_MI_IO_FUSION=1; every subdomain in the fused kernel): the entry gather, y1 = A12 x2, x1 -= ... and
-  // the exit scatter of the interior part ride on the load / store of the two interior solves.  Measured neutral at 256^3
-  // (29.19 vs 29.35 ms: the scattered accesses cost the fused kernel what the separate kernels took), hence off by default.
-  const bool io_fused = n_fsubs_ > 0 && merged_.nsubs == 0 && (int64_t)n_fsubs_ == (int64_t)my_sds_.size() &&
-                        std::getenv("HYMLS_MI_IO_FUSION") != nullptr;
   if (profiling) dev::mark(0, true);
-  if (!io_fused) dev::gather(n1_, d_inperm_, b, z1);        // b1
-  dev::gather(n2_, d_inperm_ + n1_, b, z2);                 // b2
+  for (int v = 0; v < nv; v++) {
+    dev::gather(n1_, d_inperm_, b + v * ldb, z1 + v * ldz);        // b1
+    dev::gather(n2_, d_inperm_ + n1_, b + v * ldb, z2 + v * ldz);  // b2
+  }
   if (profiling) dev::mark(1, true);
-  if (io_fused) {
-    dev::FusedIO io; io.in = 1; io.b = b; io.perm = d_inperm_;
-    dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, z1, &io);
-  } else {
-    interior_solve(z1);                                     // x1 = A11 \ b1
-  }
+  interior_solve_mv(z1, ldz, nv);                                  // x1 = A11 \ b1
   if (profiling) { dev::mark(1, false); dev::mark(2, true); }
-  xch_int_.forward(z1, z1);                                 // halo: interior layer of the neighbouring ranks
-  dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1, z2, -1.0, 1.0, (int64_t)a21_col_.size());  // b2 - A21 x1
-  if (profiling) { dev::mark(2, false); dev::mark(3, true); }
-  schur_apply(z2, d_t2_);                                   // x2
-  if (profiling) { dev::mark(3, false); dev::mark(2, true); }
-  xch_sep_.forward(d_t2_, d_t2_);                           // halo: separators owned by the neighbouring ranks
-  if (io_fused) {
-    if (profiling) { dev::mark(2, false); dev::mark(1, true); }
-    dev::FusedIO io; io.in = 2; io.a_row = d_a12_row_; io.a_col = d_a12_col_; io.a_val = d_a12_val_; io.x2 = d_t2_;
-    io.out = 1; io.z = z1; io.user = x; io.perm = d_inperm_;
-    dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, d_t1_, &io);   // x[..] = x1 - A11 \ (A12 x2)
-    if (profiling) dev::mark(1, false);
-  } else {
-    dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_, d_t1_, 1.0, 0.0, (int64_t)a12_col_.size());  // y1 = A12 x2
-    if (profiling) { dev::mark(2, false); dev::mark(1, true); }
-    interior_solve(d_t1_);                                  // A11 \ y1
-    if (profiling) dev::mark(1, false);
-    dev::axpby(n1_, -1.0, d_t1_, 1.0, z1);                  // x1 -= ...
-    dev::scatter(n1_, d_inperm_, z1, x);
+  for (int v = 0; v < nv; v++) {
+    xch_int_.forward(z1 + v * ldz, z1 + v * ldz);                  // halo: interior layer of the neighbouring ranks
+    dev::spmv(n2_, d_a21_row_, d_a21_col_, d_a21_val_, z1 + v * ldz, z2 + v * ldz, -1.0, 1.0, (int64_t)a21_col_.size());  // b2 - A21 x1
   }
-  dev::scatter(n2_, d_inperm_ + n1_, d_t2_, x);
+  if (profiling) { dev::mark(2, false); dev::mark(3, true); }
+  schur_apply(z2, ldz, d_t2_, ld2, nv);                            // x2
+  if (profiling) { dev::mark(3, false); dev::mark(2, true); }
+  for (int v = 0; v < nv; v++) {
+    xch_sep_.forward(d_t2_ + v * ld2, d_t2_ + v * ld2);            // halo: separators owned by the neighbouring ranks
+    dev::spmv(n1_, d_a12_row_, d_a12_col_, d_a12_val_, d_t2_ + v * ld2, d_t1_ + v * ld1, 1.0, 0.0, (int64_t)a12_col_.size());  // y1 = A12 x2
+  }
+  if (profiling) { dev::mark(2, false); dev::mark(1, true); }
+  interior_solve_mv(d_t1_, ld1, nv);                               // A11 \ y1
+  if (profiling) dev::mark(1, false);
+  for (int v = 0; v < nv; v++) {
+    dev::axpby(n1_, -1.0, d_t1_ + v * ld1, 1.0, z1 + v * ldz);     // x1 -= ...
+    dev::scatter(n1_, d_inperm_, z1 + v * ldz, x + v * ldx);
+    dev::scatter(n2_, d_inperm_ + n1_, d_t2_ + v * ld2, x + v * ldx);
+  }
   if (profiling) dev::mark(0, false);
 }
 
@@ -1833,6 +1881,7 @@ void LevelSolver::set_next_border() {
 
 void LevelSolver::next_apply_bordered(const double* rhs, const double* T, double* sol, double* S) {
   if (!comm_->distributed()) { next_->apply_inverse_bordered(rhs, T, sol, S); return; }
+  ensure_nvec(1);
   xch_down_.forward(rhs, d_nrhs_);
   next_->apply_inverse_bordered(d_nrhs_, T, d_nsol_, S);
   if (next_is_direct_) {

@@ -41,6 +41,7 @@ struct BatchedLU {
   int32_t nent = 0;
   int32_t chunk = 0;              // members factored per pass
   bool packed = false;            // panels repacked after the factorisation (classes solved by the fused kernel)
+  int contrib_nv = 1;             // columns of contribution scratch (several right-hand sides in the task kernels)
   ~BatchedLU();
   void upload(int64_t scratch_budget_doubles, bool with_sblock);
   // numeric factorisation of members [b0,b0+nbc) (scratch slots 0..nbc-1)
@@ -64,7 +65,8 @@ struct MergedSolve {
   ~MergedSolve();
   // (index of the batch's plan in the PlanD table handed to solve(), batch)
   void build(const std::vector<std::pair<int32_t, const BatchedLU*>>& classes);
-  void solve(const dev::PlanD* d_plans, double* x, double* y) const;
+  void solve(const dev::PlanD* d_plans, double* x, double* y, int64_t ld, int nv) const;
+  int max_nv = 1;   // widest column group the contribution scratch of the batches holds
 };
 bool merged_solve_fits(const ClassPlan& plan);   // every front within the LDS limits of the task kernels
 
@@ -72,6 +74,10 @@ class Operator {  // something with ApplyInverse on device vectors in its own ro
  public:
   virtual ~Operator() {}
   virtual void apply_inverse(const double* b, double* x) = 0;
+  // nv right-hand sides, column-major with leading dimensions (Epetra_MultiVector); default: column by column
+  virtual void apply_inverse_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv) {
+    for (int v = 0; v < nv; v++) apply_inverse(b + v * ldb, x + v * ldx);
+  }
   // BorderedOperator (reference src/HYMLS_BorderedOperator.hpp): [K V; W' C]; V, W: device arrays (size() x m,
   // column-major, the operator's vector layout), C: host m x m column-major; m = 0 removes the border.  Takes effect
   // with the next compute of the owner.  apply_inverse_bordered: T and S are host vectors of length m.
@@ -93,6 +99,7 @@ class DirectSolver : public Operator {
                bool border_pending = false);
   ~DirectSolver() override;
   void apply_inverse(const double* b, double* x) override;
+  void apply_inverse_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv) override;
   void set_border(int m, const double* dV, const double* dW, const double* C) override;
   void apply_inverse_bordered(const double* b, const double* T, double* x, double* S) override;
   int64_t size() const override { return n_; }
@@ -100,7 +107,9 @@ class DirectSolver : public Operator {
 
  private:
   void solve(const double* b, double* x, bool zero_fixed);
+  void solve_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv, bool zero_fixed);
   int32_t n_ = 0;
+  int nv_alloc_ = 0;
   // border: x = A^{-1} b - Z y, y = (C - W' Z)^{-1} (T - W' A^{-1} b), Z = A^{-1} V
   int bm_ = 0;
   double *d_bZ_ = nullptr, *d_bW_ = nullptr;
@@ -140,6 +149,7 @@ class LevelSolver : public Operator {
   void set_values(const dvec& val);     // SetMatrix with unchanged pattern
   // b, x: this rank's owned rows (interiors of its subdomains + separators it owns) in the order of owned_gids()
   void apply_inverse(const double* b, double* x) override;
+  void apply_inverse_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv) override;
   void set_border(int m, const double* dV, const double* dW, const double* C) override;
   void apply_inverse_bordered(const double* b, const double* T, double* x, double* S) override;
   bool have_border() const { return bm_ > 0; }
@@ -172,8 +182,11 @@ class LevelSolver : public Operator {
   void build_schur_setup();
   void exchange_records();
   void assemble_reduced(Csr& R, ivec& row_gids, dvec* tvn);
-  void schur_apply(double* rhs2, double* x2);
-  void next_apply(const double* rhs, double* sol);
+  void schur_apply(double* rhs2, int64_t ldr, double* x2, int64_t ldx, int nv);
+  void next_apply(const double* rhs, double* sol, int64_t ld, int nv);
+  void interior_solve_mv(double* x1, int64_t ld, int nv);
+  void ensure_nvec(int nv);
+  int nvec_alloc_ = 1;
   void build_handoff(const ivec& next_owned);
   void interior_solve(double* x1);
   void interior_solve_transposed(double* x1);
@@ -236,7 +249,7 @@ class LevelSolver : public Operator {
   // fused interior solve tables
   dev::FusedSub* d_fsubs_ = nullptr;
   dev::PlanD* d_fplans_ = nullptr;
-  int32_t n_fsubs_ = 0, fused_lds_ = 0;
+  int32_t n_fsubs_ = 0, fused_lds_ = 0, fused_front_lds_ = 0, fused_vec_lds_ = 0;
   std::vector<char> cls_fused_;
   // merged level solve tables (classes too large for the fused kernel)
   std::vector<char> cls_merged_;

@@ -503,5 +503,28 @@ void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t, const double* x
   }
 }
 
+
+// several right-hand sides: the simulator walks over the columns; column v uses its own contribution scratch
+// (cstride doubles behind that of column v - 1, as in the HIP kernels)
+static std::vector<LvlSub> column_subs(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, int v) {
+  int32_t ns = 0;
+  for (int32_t t = 0; t < ntasks; t++) ns = std::max(ns, tasks[t].sub + 1);
+  std::vector<LvlSub> out(subs, subs + ns);
+  for (auto& s : out) s.contrib += (int64_t)v * s.cstride;
+  return out;
+}
+void interior_solve_fused_mv(int32_t nsub, const FusedSub* subs, const PlanD* plans, int32_t lds_doubles, int32_t, double* x, int64_t ldx, int nv) {
+  for (int v = 0; v < nv; v++) interior_solve_fused(nsub, subs, plans, lds_doubles, x + v * ldx, nullptr);
+}
+void solve_fwd_tasks_mv(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds, const double* x, double* y, int64_t ld, int nv) {
+  for (int v = 0; v < nv; v++) { auto sv = column_subs(tasks, ntasks, subs, v); solve_fwd_tasks(tasks, ntasks, sv.data(), plans, lds, x + v * ld, y + v * ld); }
+}
+void solve_bwd_tasks_mv(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds, const double* y, double* x, int64_t ld, int nv) {
+  for (int v = 0; v < nv; v++) { auto sv = column_subs(tasks, ntasks, subs, v); solve_bwd_tasks(tasks, ntasks, sv.data(), plans, lds, y + v * ld, x + v * ld); }
+}
+void blocks_apply_all_mv(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, int64_t ldx, double* y, int64_t ldy, int nv) {
+  for (int v = 0; v < nv; v++) blocks_apply_all(nblk, blocks, max_nb, x + v * ldx, y + v * ldy);
+}
+
 }  // namespace dev
 }  // namespace hymls

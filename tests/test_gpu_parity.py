@@ -351,6 +351,39 @@ def test_builtin_rccl_transport_single_rank(gpu_lib, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,sx,levels,cx,part,env", [
+    ("Laplace", 16, 4, 2, 2, "Cartesian", {}),
+    ("Stokes-C", 16, 8, 1, -1, "Skew Cartesian", {}),
+    ("Stokes-C", 32, 4, 2, 2, "Skew Cartesian", {}),
+    ("Stokes-C", 16, 8, 1, -1, "Skew Cartesian", {"HYMLS_MI_NO_FUSED_SOLVE": "1"}),                       # task kernels on level 0
+    ("Stokes-C", 16, 8, 1, -1, "Skew Cartesian", {"HYMLS_MI_NO_FUSED_SOLVE": "1", "HYMLS_MI_LVL_SMALL_ROWS": "32"}),   # 64-row tiles
+])
+def test_multivector_apply_inverse_gpu(gpu_lib, monkeypatch, eq, n, sx, levels, cx, part, env):
+    """several right-hand sides in one ApplyInverse (reference src/HYMLS_MatrixBlock.cpp:335-344, Preconditioner.cpp:
+    997-1002): the multi-vector kernels (factor panels read once per group of up to 4 columns) against the oracle and
+    against the single-vector kernels, nvec = 2, 3, 4, 5, 8; host blocks and device tensors."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    A, tv = problem(eq, n)
+    P = product_prec(A, tv, xml_params(eq, n, sx, levels, cx=cx, partitioner=part), gpu_lib)
+    O = oracle_prec(A, tv, eq, n, sx, levels, cx=cx, partitioner=part)
+    rng = np.random.default_rng(8)
+    for nvec in (2, 3, 4, 5, 8):
+        B = rng.uniform(-1, 1, (A.shape[0], nvec))
+        X = P.ApplyInverse(B)
+        for j in range(nvec):
+            x1 = P.ApplyInverse(B[:, j].copy())
+            assert rel_diff(X[:, j], x1) < 1e-12                      # (summation order differs from the single-vector kernels)
+        for j in (0, nvec - 1):
+            assert rel_diff(X[:, j], O.apply_inverse(B[:, j])) < 1e-8
+        Bd = torch.from_numpy(np.ascontiguousarray(B.T)).cuda()       # (nvec, n) row-major = column-major (n, nvec)
+        Xd = P.ApplyInverse(Bd)
+        torch.cuda.synchronize()
+        assert np.array_equal(Xd.cpu().numpy().T, X)
+
+
+@pytest.mark.gpu
 def test_two_live_handles_alternate(gpu_lib):
     """every handle owns its device context (stream, arenas, profiling marks): two preconditioners alive at the same
     time, applied alternately, give exactly what each gives alone (reference: any number of Preconditioner objects)."""

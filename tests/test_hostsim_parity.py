@@ -232,3 +232,20 @@ def test_tiled_separator_block_apply(hostsim_lib, monkeypatch):
     monkeypatch.setenv("HYMLS_MI_BLOCK_TILE_MIN", "8")
     x_tiled = product_prec(A, tv, prm, hostsim_lib).ApplyInverse(b)
     assert rel_diff(x_tiled, x_plain) < 1e-13
+
+
+@pytest.mark.parametrize("eq,n,sx,levels,cx,part", [("Laplace", 16, 4, 2, 2, "Cartesian"), ("Stokes-C", 16, 8, 1, -1, "Skew Cartesian")])
+def test_multivector_apply_inverse(hostsim_lib, eq, n, sx, levels, cx, part):
+    """ApplyInverse on an Epetra_MultiVector-like block (reference src/HYMLS_MatrixBlock.cpp:335-344: numvec columns):
+    every column equals the single-vector result and the oracle's; strided host blocks and any nvec."""
+    A, tv = problem(eq, n)
+    P = product_prec(A, tv, xml_params(eq, n, sx, levels, cx=cx, partitioner=part), hostsim_lib)
+    O = oracle_prec(A, tv, eq, n, sx, levels, cx=cx, partitioner=part)
+    rng = np.random.default_rng(8)
+    for nvec in (2, 5, 9):
+        B = rng.uniform(-1, 1, (A.shape[0], nvec))
+        X = P.ApplyInverse(B)
+        assert X.shape == B.shape
+        for j in range(nvec):
+            assert np.array_equal(X[:, j], P.ApplyInverse(B[:, j].copy()))
+        assert rel_diff(X[:, nvec - 1], O.apply_inverse(B[:, nvec - 1])) < 1e-8

@@ -38,6 +38,9 @@ def cpu_baseline(problem, re, n, sx, levels, seconds_budget=30.0):
     from oracle import galeri, cpu_oracle
     from oracle.partition import Params
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the GPU box grants 16 host cores per GPU whatever the affinity mask says (and 256 threads on a 0.4 M DoF sample
+    # are slower than one: measured 0.41 against 8.0 MDoF/s)
+    cores = max(1, min(cores, int(os.environ.get("HYMLS_CPU_BASELINE_THREADS", "16"))))
     try:
         lib = cpu_oracle.load(cpu_oracle.build(native=True, out_dir=tempfile.mkdtemp(prefix="hymls_cpu_")))
     except Exception:  # pragma: no cover  (no compiler on the box: the portable build made by __graft_entry__.build())

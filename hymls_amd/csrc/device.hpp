@@ -194,7 +194,10 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
 struct LvlSub { const double* fac; double* contrib; int32_t xoff, cls; int64_t cstride; };   // one (class, member); cstride: distance of
                                                                                              // the contribution vectors of two columns
 struct LvlTask { int32_t sub, front, r0, pad; };   // r0 < 0: whole front; else rows [r0, r0 + 64)
-constexpr int LVL_MAX_ROWS = 19000;                // w + ri limit of a front on this path (LDS vector: 152 KiB of the 160)
+constexpr int LVL_MAX_ROWS = 6144;                 // w + ri limit of a front on this path (LDS vector).  Measured: with wider
+                                                   // fronts (one 216 k-unknown system, root front 7 k wide) a 64-row tile task
+                                                   // streams megabytes through ONE workgroup and the level takes longer than
+                                                   // the column-split panel kernels of the big-front path, launch chain included
 constexpr int LVL_SMALL_ROWS = 256;                // fronts up to this many rows are one task
 // y[pivots] = forward-substituted values, contributions pushed to the parents' assembly
 void solve_fwd_tasks(const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t lds_doubles,

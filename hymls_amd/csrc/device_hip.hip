@@ -373,10 +373,25 @@ __device__ void wg_gemm(double* __restrict__ C, int64_t ldc, const double* __res
   __syncthreads();
 }
 
+// element growth of an LU without pivoting (w x w block, column-major with leading dimension ld, factored in place):
+// flags 2 in *flag when a multiplier or an entry of U exceeds GROWTH_LIMIT times the largest entry of the block
+// before the factorisation -- the factor would be inaccurate without anybody noticing (high Reynolds numbers: the
+// reference's KLU would pivot there).  m0: max |entry| before, filled by growth_before().
+constexpr double GROWTH_LIMIT = 1e8;
+__device__ inline void block_absmax(const double* S, int64_t ld, int w, bool lower, bool upper, unsigned long long* acc) {
+  double m = 0.0;
+  for (int t = threadIdx.x; t < w * w; t += blockDim.x) {
+    const int i = t % w, j = t / w;
+    if ((i > j && lower) || (i <= j && upper)) m = fmax(m, fabs(S[i + ld * j]));
+  }
+  atomicMax(acc, (unsigned long long)__double_as_longlong(m));
+}
+
 __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const int32_t* __restrict__ list, int32_t b0,
                                                       const double* __restrict__ kval) {
   __shared__ double lds[STAGE_DOUBLES + 2 * GEMM_KB * 64];
   __shared__ int s_bad;
+  __shared__ unsigned long long s_m0, s_ml, s_mu;
   const int tid = threadIdx.x;
   const int slot = blockIdx.y;
   const int b = b0 + slot;
@@ -385,7 +400,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
   double* sc = B.scratch + (int64_t)slot * P.scratch_size;
   double* A = sc + F.f_off;
   const int64_t mm = (int64_t)m * m;
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) { s_bad = 0; s_m0 = 0; s_ml = 0; s_mu = 0; }
   // 1. zero, assemble matrix entries and the children's update matrices
   for (int64_t t = tid; t < mm; t += FT) A[t] = 0.0;
   __syncthreads();
@@ -413,6 +428,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     double* xv = lds + w * w;
     for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + (int64_t)m * (t / w)];
     __syncthreads();
+    block_absmax(S, w, w, true, true, &s_m0);
     for (int k = 0; k < w; k++) {
       const double piv = S[k + w * k];
       if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
@@ -427,6 +443,11 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       }
       __syncthreads();
     }
+    block_absmax(S, w, w, true, false, &s_ml);
+    block_absmax(S, w, w, false, true, &s_mu);
+    __syncthreads();
+    if (tid == 0 && (__longlong_as_double((long long)s_ml) > GROWTH_LIMIT ||
+                     __longlong_as_double((long long)s_mu) > GROWTH_LIMIT * __longlong_as_double((long long)s_m0))) s_bad |= 2;
     for (int j = w - 2; j >= 0; j--) {
       for (int i = j + 1 + tid; i < w; i += FT) xv[i] = S[i + w * j];
       __syncthreads();
@@ -452,6 +473,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     for (int t = tid; t < w * w; t += FT) Lp[(t % w) + ld * (t / w)] = S[t];
   } else {
     // 2. LU (no pivoting) of the w x w pivot block in global memory (wide pivot blocks)
+    block_absmax(A, m, w, true, true, &s_m0);
     for (int k = 0; k < w; k++) {
       const double piv = A[k + (int64_t)m * k];
       if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
@@ -466,6 +488,11 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       }
       __syncthreads();
     }
+    block_absmax(A, m, w, true, false, &s_ml);
+    block_absmax(A, m, w, false, true, &s_mu);
+    __syncthreads();
+    if (tid == 0 && (__longlong_as_double((long long)s_ml) > GROWTH_LIMIT ||
+                     __longlong_as_double((long long)s_mu) > GROWTH_LIMIT * __longlong_as_double((long long)s_m0))) s_bad |= 2;
     // 3. triangular inverses into the factor slab: strictly lower = L11^{-1}, upper = U11^{-1}
     for (int t = tid; t < w; t += FT) {
       for (int i = t + 1; i < w; i++) {
@@ -481,7 +508,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       }
     }
   }
-  if (s_bad && tid == 0) atomicExch(B.flag, 1);
+  if (s_bad && tid == 0) atomicOr(B.flag, s_bad);
   __threadfence_block();
   __syncthreads();
   if (r > 0) {
@@ -617,15 +644,17 @@ __global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64
                                                   double* __restrict__ tmp0, int64_t strideT, int32_t* flag) {
   extern __shared__ double S[];          // wk x wk block (column-major) + wk work vector
   __shared__ int s_bad;
+  __shared__ unsigned long long s_m0, s_ml, s_mu;
   const int tid = threadIdx.x, slot = blockIdx.x, w = wk;
   double* A = A0 + (int64_t)slot * strideA;
   double* Sb = slab0 + (int64_t)slot * strideS;
   double* Lf = tmp0 + (int64_t)slot * strideT;
   double* Uf = Lf + (int64_t)PIECE * PIECE;
   double* xv = S + w * w;
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) { s_bad = 0; s_m0 = 0; s_ml = 0; s_mu = 0; }
   for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + ld * (t / w)];
   __syncthreads();
+  block_absmax(S, w, w, true, true, &s_m0);
   // right-looking LU
   for (int k = 0; k < w; k++) {
     const double piv = S[k + w * k];
@@ -641,7 +670,12 @@ __global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64
     }
     __syncthreads();
   }
-  if (s_bad && tid == 0) atomicExch(flag, 1);
+  block_absmax(S, w, w, true, false, &s_ml);
+  block_absmax(S, w, w, false, true, &s_mu);
+  __syncthreads();
+  if (tid == 0 && (__longlong_as_double((long long)s_ml) > GROWTH_LIMIT ||
+                   __longlong_as_double((long long)s_mu) > GROWTH_LIMIT * __longlong_as_double((long long)s_m0))) s_bad |= 2;
+  if (s_bad && tid == 0) atomicOr(flag, s_bad);
   // in-place inverse of the unit lower factor: columns from the last to the first,
   // X[j+1:, j] = - X[j+1:, j+1:] * L[j+1:, j]   (X[j+1:, j+1:] already holds the inverse)
   for (int j = w - 2; j >= 0; j--) {

@@ -360,7 +360,11 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   lu_->upload(SCRATCH_BUDGET, false);
   d_val_ = dev::upload(A.val);
   lu_->factor_chunk(d_val_, 0, 1);
-  HYMLS_CHECK(lu_->check_flag() == 0, -4, "coarse factorisation hit a zero or non-finite pivot");
+  {
+    const int32_t f = lu_->check_flag();
+    HYMLS_CHECK((f & 1) == 0, -4, "coarse factorisation hit a zero or non-finite pivot");
+    HYMLS_CHECK((f & 2) == 0, -4, "coarse factorisation without pivoting is unstable for this matrix: element growth above 1e8");
+  }
   d_perm_ = dev::upload(lu_->plan.perm);
   // the tree levels of one large system are launch-latency bound with one launch chain per level (assemble, panels,
   // finalize, small fronts: about 100 launches per solve at 216 k unknowns); the merged task kernels need one launch
@@ -1498,11 +1502,13 @@ void LevelSolver::compute() {
     }
   }
   if (side) dev::join_streams();
-  int32_t bad = 0;
-  for (auto& cp : cls_) if (cp->lu.check_flag() != 0) bad = 1;
+  int32_t bad = 0, grown = 0;
+  for (auto& cp : cls_) { const int32_t f = cp->lu.check_flag(); bad |= (f & 1); grown |= (f & 2) >> 1; }
   // (collective: every rank has to reach the exchanges below, so errors are agreed on first)
   HYMLS_CHECK(comm_->allsum(bad) == 0, -4, "subdomain factorisation hit a zero or non-finite pivot (level " +
                                                std::to_string(level_) + ")");
+  HYMLS_CHECK(comm_->allsum(grown) == 0, -4, "subdomain factorisation without pivoting is unstable for this matrix: element growth "
+                                             "above 1e8 (level " + std::to_string(level_) + "); the factor would be inaccurate");
   lap("factor + transform + extract");
   compute_border();
   exchange_records();

@@ -384,6 +384,29 @@ def test_multivector_apply_inverse_gpu(gpu_lib, monkeypatch, eq, n, sx, levels, 
 
 
 @pytest.mark.gpu
+def test_unstable_pivot_free_factorisation_is_reported(gpu_lib):
+    """the subdomain LU runs without numerical pivoting (the reference runs KLU with pivot tolerance 0 on its F-matrix
+    ordering, src/HYMLS_SparseDirectSolver.cpp:244-254); element growth above 1e8 is detected on the device and Compute
+    returns -4 instead of handing out a silently inaccurate factor.  Matrix: the Laplace couplings with a diagonal of
+    1e-11 (every first pivot of a leaf is tiny); a benign shift of the same pattern factors fine."""
+    import hymls_amd
+    import scipy.sparse as sp
+    n = 8
+    A, tv = problem("Laplace", n)
+    off = A - sp.diags(A.diagonal())
+    prm = xml_params("Laplace", n, 4, 1)
+    bad = (off + 1e-11 * sp.identity(A.shape[0])).tocsr()
+    with pytest.raises(hymls_amd.HymlsError) as e:
+        product_prec(bad, tv, prm, gpu_lib)
+    assert e.value.code == -4 and "unstable" in str(e.value)
+    good = (off - 7.0 * sp.identity(A.shape[0])).tocsr()
+    P = product_prec(good, tv, prm, gpu_lib)
+    O = oracle_prec(good, tv, "Laplace", n, 4, 1)
+    b = np.random.default_rng(2).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-10
+
+
+@pytest.mark.gpu
 def test_two_live_handles_alternate(gpu_lib):
     """every handle owns its device context (stream, arenas, profiling marks): two preconditioners alive at the same
     time, applied alternately, give exactly what each gives alone (reference: any number of Preconditioner objects)."""

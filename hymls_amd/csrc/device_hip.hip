@@ -1723,6 +1723,11 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
 // single-vector ones with the per-row state (accumulators, LDS vectors) replicated NV times.  A launcher picks the
 // widest group (4, 2, 1) whose LDS fits and walks over the columns.
 constexpr size_t LDS_LIMIT_BYTES = 160 * 1024;
+// widest column group of a launcher (development switch: HYMLS_MI_MV_GROUP_<FUSED|LVL|BLK> = 1, 2 or 4)
+static int mv_group_cap(const char* which) {
+  const char* e = std::getenv((std::string("HYMLS_MI_MV_GROUP_") + which).c_str());
+  return e ? std::max(1, std::atoi(e)) : NV_MAX;
+}
 
 template <int NV>
 __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
@@ -1986,7 +1991,7 @@ void interior_solve_fused_mv(int32_t nsub, const FusedSub* subs, const PlanD* pl
   int v = 0;
   while (v < nv) {
     int g = nv - v >= 4 ? 4 : (nv - v >= 2 ? 2 : 1);
-    while (g > 1 && per * g + fixed > LDS_LIMIT_BYTES) g >>= 1;
+    while (g > 1 && (per * g + fixed > LDS_LIMIT_BYTES || g > mv_group_cap("FUSED"))) g >>= 1;
     double* xv = x + (int64_t)v * ldx;
     if (g == 4) launch_fused_mv<4>(nsub, subs, plans, per * 4 + fixed, xv, ldx);
     else if (g == 2) launch_fused_mv<2>(nsub, subs, plans, per * 2 + fixed, xv, ldx);
@@ -2000,7 +2005,7 @@ void interior_solve_fused_mv(int32_t nsub, const FusedSub* subs, const PlanD* pl
 template <int NV>
 __global__ void __launch_bounds__(256) k_lvl_fwd_mv(const LvlTask* __restrict__ tasks, const LvlSub* __restrict__ subs,
                                                      const PlanD* __restrict__ plans, const double* __restrict__ x,
-                                                     double* __restrict__ y, int64_t ld, int32_t LS) {
+                                                     double* __restrict__ y, int64_t ld, int32_t LS, int32_t c0) {
   extern __shared__ double f[];     // [NV][LS]
   const LvlTask T = tasks[blockIdx.x];
   const LvlSub S = subs[T.sub];
@@ -2010,8 +2015,8 @@ __global__ void __launch_bounds__(256) k_lvl_fwd_mv(const LvlTask* __restrict__ 
   const int64_t ldp = rows;
   const double* xb = x + S.xoff;
   double* yb = y + S.xoff;
-  double* cb = S.contrib;
   const int64_t cs = S.cstride;
+  double* cb = S.contrib + (int64_t)c0 * cs;   // contribution vectors of the columns c0 .. c0 + NV - 1 of the whole block
   const int32_t* __restrict__ aptr = P->asm_ptr + F.a_off;
   const int32_t* __restrict__ asrc = P->asm_src;
   const double* __restrict__ Lp = S.fac + F.lp_off;
@@ -2218,11 +2223,11 @@ __global__ void __launch_bounds__(256) k_lvl_bwd_mv(const LvlTask* __restrict__ 
 
 template <int NV>
 static void launch_lvl_mv(bool fwd, const LvlTask* tasks, int32_t ntasks, const LvlSub* subs, const PlanD* plans, int32_t ls,
-                          const double* a, double* b, int64_t ld) {
+                          const double* a, double* b, int64_t ld, int32_t c0) {
   const size_t shm = (size_t)ls * NV * sizeof(double);
   if (fwd) {
     if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_lvl_fwd_mv<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(k_lvl_fwd_mv<NV>, dim3(ntasks), dim3(256), shm, g_stream, tasks, subs, plans, a, b, ld, ls);
+    hipLaunchKernelGGL(k_lvl_fwd_mv<NV>, dim3(ntasks), dim3(256), shm, g_stream, tasks, subs, plans, a, b, ld, ls, c0);
   } else {
     if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_lvl_bwd_mv<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(k_lvl_bwd_mv<NV>, dim3(ntasks), dim3(256), shm, g_stream, tasks, subs, plans, a, b, ld, ls);
@@ -2235,13 +2240,15 @@ static void lvl_tasks_mv(bool fwd, const LvlTask* tasks, int32_t ntasks, const L
   int v = 0;
   while (v < nv) {
     int g = nv - v >= 4 ? 4 : (nv - v >= 2 ? 2 : 1);
-    while (g > 1 && (size_t)lds_doubles * g * sizeof(double) > LDS_LIMIT_BYTES) g >>= 1;
+    while (g > 1 && ((size_t)lds_doubles * g * sizeof(double) > LDS_LIMIT_BYTES || g > mv_group_cap("LVL"))) g >>= 1;
     const double* av = a + (int64_t)v * ld;
     double* bv = b + (int64_t)v * ld;
-    if (g == 4) launch_lvl_mv<4>(fwd, tasks, ntasks, subs, plans, lds_doubles, av, bv, ld);
-    else if (g == 2) launch_lvl_mv<2>(fwd, tasks, ntasks, subs, plans, lds_doubles, av, bv, ld);
-    else if (fwd) solve_fwd_tasks(tasks, ntasks, subs, plans, lds_doubles, av, bv);
-    else solve_bwd_tasks(tasks, ntasks, subs, plans, lds_doubles, av, bv);
+    // (every column of the block keeps its own contribution vectors between the tree levels: slot = column index)
+    if (g == 4) launch_lvl_mv<4>(fwd, tasks, ntasks, subs, plans, lds_doubles, av, bv, ld, v);
+    else if (g == 2) launch_lvl_mv<2>(fwd, tasks, ntasks, subs, plans, lds_doubles, av, bv, ld, v);
+    else if (!fwd) solve_bwd_tasks(tasks, ntasks, subs, plans, lds_doubles, av, bv);    // (the backward sweep reads no contributions)
+    else if (v == 0) solve_fwd_tasks(tasks, ntasks, subs, plans, lds_doubles, av, bv);
+    else launch_lvl_mv<1>(fwd, tasks, ntasks, subs, plans, lds_doubles, av, bv, ld, v);
     v += g;
   }
 }
@@ -2543,7 +2550,7 @@ void blocks_apply_all_mv(int32_t nblk, const BlkD* blocks, int32_t max_nb, const
   int v = 0;
   while (v < nv) {
     int g = nv - v >= 4 ? 4 : (nv - v >= 2 ? 2 : 1);
-    while (g > 1 && (size_t)max_nb * g * sizeof(double) > 64 * 1024) g >>= 1;
+    while (g > 1 && ((size_t)max_nb * g * sizeof(double) > 64 * 1024 || g > mv_group_cap("BLK"))) g >>= 1;
     const double* xv = x + (int64_t)v * ldx;
     double* yv = y + (int64_t)v * ldy;
     const size_t shm = (size_t)max_nb * g * sizeof(double);

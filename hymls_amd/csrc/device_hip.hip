@@ -1785,9 +1785,9 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
         const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
-        double a[2][NV];
+        double a[4][NV];    // (the accumulation order of the single-vector kernel: bitwise the same column)
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+        for (int u = 0; u < 4; u++)
 #pragma unroll
           for (int v = 0; v < NV; v++) a[u][v] = 0.0;
         int k = 0;
@@ -1798,7 +1798,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
 #pragma unroll
           for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int v = 0; v < NV; v++) a[u & 1][v] += l[u] * f[v * FS + k + u];
+            for (int v = 0; v < NV; v++) a[u][v] += l[u] * f[v * FS + k + u];
         }
         for (; k < kmax; k++) {
           const double l = p[c1 * k - tri * ((k * (k + 3)) >> 1)];
@@ -1807,16 +1807,16 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-          const double sum = a[0][v] + a[1][v];
+          const double sum = (a[0][v] + a[1][v]) + (a[2][v] + a[3][v]);
           if (r < w) X[v * nI + F.c0 + r] = f[v * FS + r] + sum; else C[v * CS + F.c_off + r - w] -= sum;
         }
       }
     } else {
       const int RT = ni > 64 ? 128 : 64, KG = 256 / RT;
       const int it = tid % RT, kg = tid / RT;
-      double a0[NV], a1[NV];
+      double a0[NV], a1[NV], a2[NV], a3[NV];
 #pragma unroll
-      for (int v = 0; v < NV; v++) { a0[v] = 0.0; a1[v] = 0.0; }
+      for (int v = 0; v < NV; v++) { a0[v] = 0.0; a1[v] = 0.0; a2[v] = 0.0; a3[v] = 0.0; }
       if (it < ni) {
         const int item = P.fw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
@@ -1831,8 +1831,8 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
           const double l0 = at(k), l1 = at(k + KG), l2 = at(k + 2 * KG), l3 = at(k + 3 * KG);
 #pragma unroll
           for (int v = 0; v < NV; v++) {
-            a0[v] += l0 * f[v * FS + k] + l2 * f[v * FS + k + 2 * KG];
-            a1[v] += l1 * f[v * FS + k + KG] + l3 * f[v * FS + k + 3 * KG];
+            a0[v] += l0 * f[v * FS + k]; a1[v] += l1 * f[v * FS + k + KG];
+            a2[v] += l2 * f[v * FS + k + 2 * KG]; a3[v] += l3 * f[v * FS + k + 3 * KG];
           }
         }
         for (; k < kmax; k += KG) {
@@ -1842,7 +1842,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
         }
       }
 #pragma unroll
-      for (int v = 0; v < NV; v++) Fv[v * FS + 128 + kg * RT + it] = a0[v] + a1[v];
+      for (int v = 0; v < NV; v++) Fv[v * FS + 128 + kg * RT + it] = (a0[v] + a1[v]) + (a2[v] + a3[v]);
       __syncthreads();
       if (tid < ni) {
         const int item = P.fw_items[ib + tid];
@@ -1869,9 +1869,9 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
         int c1, tri;
         const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
         const double* Xs = X + F.c0;
-        double a[2][NV];
+        double a[4][NV];
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+        for (int u = 0; u < 4; u++)
 #pragma unroll
           for (int v = 0; v < NV; v++) a[u][v] = 0.0;
         int k = i;
@@ -1882,7 +1882,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
 #pragma unroll
           for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int v = 0; v < NV; v++) a[u & 1][v] += l[u] * Xs[v * nI + k + u];
+            for (int v = 0; v < NV; v++) a[u][v] += l[u] * Xs[v * nI + k + u];
         }
         for (; k < w; k++) {
           const double l = p[c1 * k + tri * ((k * (k + 1)) >> 1)];
@@ -1899,7 +1899,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
 #pragma unroll
           for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int v = 0; v < NV; v++) a[u & 1][v] -= l[u] * X[v * nI + id[u]];
+            for (int v = 0; v < NV; v++) a[u][v] -= l[u] * X[v * nI + id[u]];
         }
         for (; k < ri; k++) {
           const double l = qv[(int64_t)w * k]; const int id = idx[k];
@@ -1907,7 +1907,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
           for (int v = 0; v < NV; v++) a[0][v] -= l * X[v * nI + id];
         }
 #pragma unroll
-        for (int v = 0; v < NV; v++) Fv[v * FS + it] = a[0][v] + a[1][v];
+        for (int v = 0; v < NV; v++) Fv[v * FS + it] = (a[0][v] + a[1][v]) + (a[2][v] + a[3][v]);
       }
       __syncthreads();
       for (int it = tid; it < ni; it += 256) {
@@ -1919,9 +1919,9 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
     } else {
       const int RT = ni > 64 ? 128 : 64, KG = 256 / RT;
       const int it = tid % RT, kg = tid / RT;
-      double a0[NV], a1[NV];
+      double a0[NV], a1[NV], a2[NV], a3[NV];
 #pragma unroll
-      for (int v = 0; v < NV; v++) { a0[v] = 0.0; a1[v] = 0.0; }
+      for (int v = 0; v < NV; v++) { a0[v] = 0.0; a1[v] = 0.0; a2[v] = 0.0; a3[v] = 0.0; }
       if (it < ni) {
         const int item = P.bw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
@@ -1931,10 +1931,13 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
         const double* Xs = X + F.c0;
         auto at = [&](int kk) { return p[c1 * kk + tri * ((kk * (kk + 1)) >> 1)]; };
         int k = i + kg;
-        for (; k + KG < w; k += 2 * KG) {
-          const double l0 = at(k), l1 = at(k + KG);
+        for (; k + 3 * KG < w; k += 4 * KG) {
+          const double l0 = at(k), l1 = at(k + KG), l2 = at(k + 2 * KG), l3 = at(k + 3 * KG);
 #pragma unroll
-          for (int v = 0; v < NV; v++) { a0[v] += l0 * Xs[v * nI + k]; a1[v] += l1 * Xs[v * nI + k + KG]; }
+          for (int v = 0; v < NV; v++) {
+            a0[v] += l0 * Xs[v * nI + k]; a1[v] += l1 * Xs[v * nI + k + KG];
+            a2[v] += l2 * Xs[v * nI + k + 2 * KG]; a3[v] += l3 * Xs[v * nI + k + 3 * KG];
+          }
         }
         for (; k < w; k += KG) {
           const double l = at(k);
@@ -1944,11 +1947,13 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
         const double* __restrict__ qv = fac + F.q_off + i;
         const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
         k = kg;
-        for (; k + KG < ri; k += 2 * KG) {
-          const double q0 = qv[(int64_t)w * k], q1 = qv[(int64_t)w * (k + KG)];
-          const int i0 = idx[k], i1 = idx[k + KG];
+        for (; k + 3 * KG < ri; k += 4 * KG) {
+          const double q0 = qv[(int64_t)w * k], q1 = qv[(int64_t)w * (k + KG)], q2 = qv[(int64_t)w * (k + 2 * KG)], q3 = qv[(int64_t)w * (k + 3 * KG)];
+          const int i0 = idx[k], i1 = idx[k + KG], i2 = idx[k + 2 * KG], i3 = idx[k + 3 * KG];
 #pragma unroll
-          for (int v = 0; v < NV; v++) { a0[v] -= q0 * X[v * nI + i0]; a1[v] -= q1 * X[v * nI + i1]; }
+          for (int v = 0; v < NV; v++) {
+            a0[v] -= q0 * X[v * nI + i0]; a1[v] -= q1 * X[v * nI + i1]; a2[v] -= q2 * X[v * nI + i2]; a3[v] -= q3 * X[v * nI + i3];
+          }
         }
         for (; k < ri; k += KG) {
           const double q0 = qv[(int64_t)w * k]; const int i0 = idx[k];
@@ -1957,7 +1962,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
         }
       }
 #pragma unroll
-      for (int v = 0; v < NV; v++) Fv[v * FS + 128 + kg * RT + it] = a0[v] + a1[v];
+      for (int v = 0; v < NV; v++) Fv[v * FS + 128 + kg * RT + it] = (a0[v] + a1[v]) + (a2[v] + a3[v]);
       __syncthreads();
       if (tid < ni) {
         const int item = P.bw_items[ib + tid];
@@ -2032,14 +2037,16 @@ __global__ void __launch_bounds__(256) k_lvl_fwd_mv(const LvlTask* __restrict__ 
     __syncthreads();
     for (int i = tid; i < rows; i += 256) {
       const int kmax = i < w ? i : w;
-      double s0[NV], s1[NV];
+      double s0[NV], s1[NV], s2[NV], s3[NV];   // (the accumulation order of the single-vector kernel)
 #pragma unroll
-      for (int v = 0; v < NV; v++) { s0[v] = 0.0; s1[v] = 0.0; }
+      for (int v = 0; v < NV; v++) { s0[v] = 0.0; s1[v] = 0.0; s2[v] = 0.0; s3[v] = 0.0; }
       int k = 0;
-      for (; k + 1 < kmax; k += 2) {
-        const double l0 = Lp[i + ldp * k], l1 = Lp[i + ldp * (k + 1)];
+      for (; k + 3 < kmax; k += 4) {
+        const double l0 = Lp[i + ldp * k], l1 = Lp[i + ldp * (k + 1)], l2 = Lp[i + ldp * (k + 2)], l3 = Lp[i + ldp * (k + 3)];
 #pragma unroll
-        for (int v = 0; v < NV; v++) { s0[v] += l0 * f[v * LS + k]; s1[v] += l1 * f[v * LS + k + 1]; }
+        for (int v = 0; v < NV; v++) {
+          s0[v] += l0 * f[v * LS + k]; s1[v] += l1 * f[v * LS + k + 1]; s2[v] += l2 * f[v * LS + k + 2]; s3[v] += l3 * f[v * LS + k + 3];
+        }
       }
       for (; k < kmax; k++) {
         const double l0 = Lp[i + ldp * k];
@@ -2048,7 +2055,7 @@ __global__ void __launch_bounds__(256) k_lvl_fwd_mv(const LvlTask* __restrict__ 
       }
 #pragma unroll
       for (int v = 0; v < NV; v++) {
-        const double s = s0[v] + s1[v];
+        const double s = (s0[v] + s1[v]) + (s2[v] + s3[v]);
         if (i < w) yb[v * ld + F.c0 + i] = f[v * LS + i] + s;
         else cb[v * cs + F.c_off + i - w] = f[v * LS + i] - s;
       }
@@ -2080,20 +2087,22 @@ __global__ void __launch_bounds__(256) k_lvl_fwd_mv(const LvlTask* __restrict__ 
   const double* __restrict__ Lr = Lp + (i < rows ? i : 0);
   const int chunk = ((kneed + 31) / 32) * 8;
   const int kb = g * chunk, ke = min(kb + chunk, kneed);
-  double acc[2][NV];
+  double acc[8][NV];
 #pragma unroll
-  for (int u = 0; u < 2; u++)
+  for (int u = 0; u < 8; u++)
 #pragma unroll
     for (int v = 0; v < NV; v++) acc[u][v] = 0.0;
   int k = kb;
   for (; k + 7 < ke; k += 8) {
     double l[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) l[u] = (k + u < krow) ? Lr[ldp * (k + u)] : 0.0;
+    for (int u = 0; u < 8; u++) l[u] = Lr[ldp * (k + u)];
 #pragma unroll
     for (int u = 0; u < 8; u++)
+      if (k + u < krow) {
 #pragma unroll
-      for (int v = 0; v < NV; v++) acc[u & 1][v] += l[u] * f[v * LS + k + u];
+        for (int v = 0; v < NV; v++) acc[u][v] += l[u] * f[v * LS + k + u];
+      }
   }
   for (; k < ke; k++) if (k < krow) {
     const double l = Lr[ldp * k];
@@ -2101,7 +2110,8 @@ __global__ void __launch_bounds__(256) k_lvl_fwd_mv(const LvlTask* __restrict__ 
     for (int v = 0; v < NV; v++) acc[0][v] += l * f[v * LS + k];
   }
 #pragma unroll
-  for (int v = 0; v < NV; v++) f[v * LS + KP + 64 + g * 64 + lane] = acc[0][v] + acc[1][v];
+  for (int v = 0; v < NV; v++)
+    f[v * LS + KP + 64 + g * 64 + lane] = ((acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v])) + ((acc[4][v] + acc[5][v]) + (acc[6][v] + acc[7][v]));
   __syncthreads();
   if (g == 0 && i < rows) {
 #pragma unroll
@@ -2138,21 +2148,29 @@ __global__ void __launch_bounds__(256) k_lvl_bwd_mv(const LvlTask* __restrict__ 
     }
     __syncthreads();
     for (int i = tid; i < w; i += 256) {
-      double s[NV], t[NV];
+      double s[NV], s0[NV], s1[NV], s2[NV], s3[NV];
 #pragma unroll
-      for (int v = 0; v < NV; v++) { s[v] = 0.0; t[v] = 0.0; }
+      for (int v = 0; v < NV; v++) { s[v] = 0.0; s0[v] = 0.0; s1[v] = 0.0; s2[v] = 0.0; s3[v] = 0.0; }
       for (int k = i; k < w; k++) {
         const double l = Lp[i + ldp * k];
 #pragma unroll
         for (int v = 0; v < NV; v++) s[v] += l * f[v * LS + k];
       }
-      for (int k = 0; k < ri; k++) {
-        const double q = Q[i + (int64_t)w * k];
+      int k = 0;
+      for (; k + 3 < ri; k += 4) {
+        const double q0 = Q[i + (int64_t)w * k], q1 = Q[i + (int64_t)w * (k + 1)], q2 = Q[i + (int64_t)w * (k + 2)], q3 = Q[i + (int64_t)w * (k + 3)];
 #pragma unroll
-        for (int v = 0; v < NV; v++) t[v] += q * f[v * LS + w + k];
+        for (int v = 0; v < NV; v++) {
+          s0[v] += q0 * f[v * LS + w + k]; s1[v] += q1 * f[v * LS + w + k + 1]; s2[v] += q2 * f[v * LS + w + k + 2]; s3[v] += q3 * f[v * LS + w + k + 3];
+        }
+      }
+      for (; k < ri; k++) {
+        const double q0 = Q[i + (int64_t)w * k];
+#pragma unroll
+        for (int v = 0; v < NV; v++) s0[v] += q0 * f[v * LS + w + k];
       }
 #pragma unroll
-      for (int v = 0; v < NV; v++) xb[v * ld + F.c0 + i] = s[v] - t[v];
+      for (int v = 0; v < NV; v++) xb[v * ld + F.c0 + i] = s[v] - ((s0[v] + s1[v]) + (s2[v] + s3[v]));
     }
     return;
   }
@@ -2169,9 +2187,9 @@ __global__ void __launch_bounds__(256) k_lvl_bwd_mv(const LvlTask* __restrict__ 
   const double* __restrict__ Qr = Q + iv;
   const int chunk = ((total + 31) / 32) * 8;
   const int kb = g * chunk, ke = min(kb + chunk, total);
-  double acc[2][NV];
+  double acc[8][NV];
 #pragma unroll
-  for (int u = 0; u < 2; u++)
+  for (int u = 0; u < 8; u++)
 #pragma unroll
     for (int v = 0; v < NV; v++) acc[u][v] = 0.0;
   {
@@ -2180,11 +2198,13 @@ __global__ void __launch_bounds__(256) k_lvl_bwd_mv(const LvlTask* __restrict__ 
     for (; k + 7 < e; k += 8) {
       double l[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) l[u] = (k + u >= lane) ? Lr[ldp * (k + u)] : 0.0;
+      for (int u = 0; u < 8; u++) l[u] = Lr[ldp * (k + u)];
 #pragma unroll
       for (int u = 0; u < 8; u++)
+        if (k + u >= lane) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) acc[u & 1][v] += l[u] * f[v * LS + k + u];
+          for (int v = 0; v < NV; v++) acc[u][v] += l[u] * f[v * LS + k + u];
+        }
     }
     for (; k < e; k++) if (k >= lane) {
       const double l = Lr[ldp * k];
@@ -2201,7 +2221,7 @@ __global__ void __launch_bounds__(256) k_lvl_bwd_mv(const LvlTask* __restrict__ 
 #pragma unroll
       for (int u = 0; u < 8; u++)
 #pragma unroll
-        for (int v = 0; v < NV; v++) acc[u & 1][v] -= l[u] * f[v * LS + k + u];
+        for (int v = 0; v < NV; v++) acc[u][v] -= l[u] * f[v * LS + k + u];
     }
     for (; k < ke; k++) {
       const double l = Qr[(int64_t)w * (k - nU)];
@@ -2210,7 +2230,8 @@ __global__ void __launch_bounds__(256) k_lvl_bwd_mv(const LvlTask* __restrict__ 
     }
   }
 #pragma unroll
-  for (int v = 0; v < NV; v++) f[v * LS + TP + g * 64 + lane] = acc[0][v] + acc[1][v];
+  for (int v = 0; v < NV; v++)
+    f[v * LS + TP + g * 64 + lane] = ((acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v])) + ((acc[4][v] + acc[5][v]) + (acc[6][v] + acc[7][v]));
   __syncthreads();
   if (g == 0 && i < w) {
 #pragma unroll
@@ -2520,9 +2541,9 @@ __global__ void __launch_bounds__(64) k_blocks_apply_all_mv(const BlkD* __restri
   const int i0 = D.r0 < 0 ? 0 : D.r0, i1 = D.r0 < 0 ? nb : min(nb, D.r0 + 64);
   for (int i = i0 + threadIdx.x; i < i1; i += 64) {
     const double* __restrict__ M = D.binv + i;
-    double a[2][NV];
+    double a[8][NV];
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int u = 0; u < 8; u++)
 #pragma unroll
       for (int v = 0; v < NV; v++) a[u][v] = 0.0;
     int j = 0;
@@ -2533,7 +2554,7 @@ __global__ void __launch_bounds__(64) k_blocks_apply_all_mv(const BlkD* __restri
 #pragma unroll
       for (int u = 0; u < 8; u++)
 #pragma unroll
-        for (int v = 0; v < NV; v++) a[u & 1][v] += l[u] * xs[v * XS + j + u];
+        for (int v = 0; v < NV; v++) a[u][v] += l[u] * xs[v * XS + j + u];
     }
     for (; j < nb; j++) {
       const double l = M[(int64_t)nb * j];
@@ -2542,7 +2563,7 @@ __global__ void __launch_bounds__(64) k_blocks_apply_all_mv(const BlkD* __restri
     }
     const int id = D.ids[i];
 #pragma unroll
-    for (int v = 0; v < NV; v++) y[v * ldy + id] = a[0][v] + a[1][v];
+    for (int v = 0; v < NV; v++) y[v * ldy + id] = ((a[0][v] + a[1][v]) + (a[2][v] + a[3][v])) + ((a[4][v] + a[5][v]) + (a[6][v] + a[7][v]));
   }
 }
 void blocks_apply_all_mv(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, int64_t ldx, double* y, int64_t ldy, int nv) {

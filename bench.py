@@ -299,7 +299,7 @@ def main():
             "data": ("synthetic (HOST SIMULATOR, TEST ONLY - not a measurement)" if args.hostsim else
                      "synthetic (REHEARSAL: all ranks share one GPU - not a multi-GPU measurement)" if args.share_gpu else "synthetic"),
             "config": {"workload": "%s %dx%dx%d, %d DoF, HYMLS %d-level "
-                                   "(Number of Levels=%d), Skew Cartesian sx=%d, Block Diagonal, 1 rhs"
+                                   "(Number of Levels=%d), Skew Cartesian sx=%d, Block Diagonal, %d rhs"
                                    % ({"stokes": "GaleriExt Stokes3D (a=nx^2,b=1)", "darcy": "GaleriExt Darcy3D (a=1,b=-1)",
                                        "cavity": "Navier-Stokes-like Jacobian Re=%g (Stokes3D + central convection, synthesised)" % args.re}[args.problem],
                                       nx, ny, nz, N_global if sharded else N_local, levels + 1, levels, sx, args.nvec),

@@ -38,10 +38,18 @@ constexpr int64_t SCRATCH_BUDGET = 1LL << 30;  // doubles (8 GiB) of frontal scr
 
 // ------------------------------------------------------------------ DropByValue
 Csr drop_by_value(const Csr& A, double tol, int kind) {
-  const bool zero_diag = kind == 1, full_diag = kind == 2;
   Csr R;
+  drop_by_value(A, tol, kind, R);
+  return R;
+}
+
+// the same into an existing matrix: its arrays are reused when the sizes have not changed (a recompute with the same
+// pattern: no allocation, no zero-filling of gigabytes)
+void drop_by_value(const Csr& A, double tol, int kind, Csr& R) {
+  const bool zero_diag = kind == 1, full_diag = kind == 2;
   R.n = A.n;
-  R.rowptr.assign(A.n + 1, 0);
+  R.rowptr.resize(A.n + 1);
+  R.rowptr[0] = 0;
   dvec diag(A.n, 0.0);
   parallel_for(A.n, [&](int64_t i) {
     for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++)
@@ -65,10 +73,9 @@ Csr drop_by_value(const Csr& A, double tol, int kind) {
   };
   parallel_for(A.n, [&](int64_t i) { R.rowptr[i + 1] = row(i, nullptr, nullptr); });
   for (int i = 0; i < A.n; i++) R.rowptr[i + 1] += R.rowptr[i];
-  R.col.resize((size_t)R.rowptr[A.n]);
-  R.val.resize((size_t)R.rowptr[A.n]);
+  if (R.col.size() != (size_t)R.rowptr[A.n]) { ivec().swap(R.col); R.col.resize((size_t)R.rowptr[A.n]); }
+  if (R.val.size() != (size_t)R.rowptr[A.n]) { dvec().swap(R.val); R.val.resize((size_t)R.rowptr[A.n]); }
   parallel_for(A.n, [&](int64_t i) { row(i, R.col.data() + R.rowptr[i], R.val.data() + R.rowptr[i]); });
-  return R;
 }
 
 // ------------------------------------------------------------------ BatchedLU
@@ -1384,10 +1391,17 @@ void LevelSolver::exchange_records() {
   if (rec_nrecv_) dev::d2d(d_ext_ + ext_recv_base_, rb, (size_t)rec_nrecv_ * sizeof(double));
 }
 
+// set_values without a copy: the level takes the array and hands back its old one (same size)
+void LevelSolver::swap_values(dvec& val) {
+  if (comm_->distributed() && initialized_) { set_values(val); return; }
+  HYMLS_CHECK(val.size() == K_.val.size(), -2, "SetMatrix: pattern changed");
+  K_.val.swap(val);
+}
+
 void LevelSolver::set_values(const dvec& val) {
   if (comm_->distributed() && initialized_) {   // values of the rows as they were given; keep the local ones
     HYMLS_CHECK(val.size() == given_nnz_, -2, "SetMatrix: pattern changed");
-    for (size_t i = 0; i < keep_entries_.size(); i++) K_.val[i] = val[keep_entries_[i]];
+    parallel_for((int64_t)keep_entries_.size(), [&](int64_t i) { K_.val[i] = val[keep_entries_[i]]; }, 1 << 16);
     return;
   }
   HYMLS_CHECK(val.size() == K_.val.size(), -2, "SetMatrix: pattern changed");
@@ -1396,7 +1410,7 @@ void LevelSolver::set_values(const dvec& val) {
 
 // the reduced matrix of all ranks: every rank contributes the rows it owns; rows in rank order,
 // columns turned into global row numbers and sorted.  On one rank this is just red_.
-void LevelSolver::assemble_reduced(Csr& R, ivec& row_gids, dvec* tvn) {
+const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
   if (!glob_ready_) {
     ivec my_gids(red_.n);
     if (direct_schur_) for (int k = 0; k < n2_; k++) my_gids[k] = gids_[sep_row_[k]];
@@ -1436,11 +1450,16 @@ void LevelSolver::assemble_reduced(Csr& R, ivec& row_gids, dvec* tvn) {
     glob_.val.assign(glob_.col.size(), 0.0);
     glob_ready_ = true;
   }
-  dvec vals = comm_->allgather(red_.val);
-  HYMLS_CHECK(vals.size() == glob_.val.size(), -3, "reduced matrix changed its pattern between two Compute calls");
-  parallel_for((int64_t)vals.size(), [&](int64_t e) { glob_.val[glob_perm_[e]] = vals[e]; }, 1 << 16);
-  R = glob_;
+  {
+    // (one rank: no copy of the 0.2 G values of a 256^3 run)
+    dvec gathered;
+    if (comm_->distributed()) gathered = comm_->allgather(red_.val);
+    const dvec& vals = comm_->distributed() ? gathered : red_.val;
+    HYMLS_CHECK(vals.size() == glob_.val.size(), -3, "reduced matrix changed its pattern between two Compute calls");
+    parallel_for((int64_t)vals.size(), [&](int64_t e) { glob_.val[glob_perm_[e]] = vals[e]; }, 1 << 16);
+  }
   row_gids = glob_gids_;
+  return glob_;
 }
 
 // vectors between this level's owners of the V-sum nodes and the next level's layout
@@ -1516,10 +1535,9 @@ void LevelSolver::compute() {
   dev::pull_sum((int64_t)red_.col.size(), d_red_pull_ptr_, d_red_pull_idx_, d_ext_, d_red_val_);
   dev::d2h(red_.val.data(), d_red_val_, red_.val.size() * sizeof(double));
   ivec next_gids;
-  Csr G;
   if (direct_schur_) {
     // Preconditioner.cpp:485-500: S assembled, DropByValue (RelZeroDiag), CoarseSolver
-    assemble_reduced(G, next_gids, nullptr);
+    const Csr& G = assemble_reduced(next_gids, nullptr);
     Csr S = drop_by_value(G, SMALL_ENTRY, 1);
     next_.reset();
     next_level_ = nullptr;
@@ -1556,13 +1574,14 @@ void LevelSolver::compute() {
     }
   }
   lap("pull + separator blocks");
-  assemble_reduced(G, next_gids, &tvn);
-  Csr R = drop_by_value(G, SMALL_ENTRY, 0);
+  const Csr& G = assemble_reduced(next_gids, &tvn);
+  Csr& R = next_R_;
+  drop_by_value(G, SMALL_ENTRY, 0, R);
   lap("reduced matrix (host)");
   if (level_ + 1 < p_.levels) {
     next_is_direct_ = false;
     if (next_level_ && next_pattern_key_rowptr_ == R.rowptr && next_pattern_key_col_ == R.col) {
-      next_level_->set_values(R.val);   // (sharded: the next level keeps the rows it needs)
+      next_level_->swap_values(R.val);   // (sharded: the next level keeps the rows it needs; R keeps a buffer of the right size)
     } else {
       next_pattern_key_rowptr_ = R.rowptr; next_pattern_key_col_ = R.col;
       next_level_ = new LevelSolver(p_.next_level(), level_ + 1, ngid_, comm_);

@@ -147,6 +147,7 @@ class LevelSolver : public Operator {
   void initialize();
   void compute();                       // uses the host values of K (uploads them)
   void set_values(const dvec& val);     // SetMatrix with unchanged pattern
+  void swap_values(dvec& val);          // the same without a copy (one rank): takes the array, hands back the old one
   // b, x: this rank's owned rows (interiors of its subdomains + separators it owns) in the order of owned_gids()
   void apply_inverse(const double* b, double* x) override;
   void apply_inverse_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv) override;
@@ -181,7 +182,7 @@ class LevelSolver : public Operator {
   void build_classes();
   void build_schur_setup();
   void exchange_records();
-  void assemble_reduced(Csr& R, ivec& row_gids, dvec* tvn);
+  const Csr& assemble_reduced(ivec& row_gids, dvec* tvn);
   void schur_apply(double* rhs2, int64_t ldr, double* x2, int64_t ldx, int nv);
   void next_apply(const double* rhs, double* sol, int64_t ld, int nv);
   void interior_solve_mv(double* x1, int64_t ld, int nv);
@@ -293,6 +294,7 @@ class LevelSolver : public Operator {
   std::vector<int64_t> glob_perm_;      // gathered entry -> entry of glob_
   std::vector<int64_t> glob_row_off_;   // first global row of every rank
   bool glob_ready_ = false;
+  Csr next_R_;                          // reduced matrix after DropByValue (kept: a recompute reuses its arrays)
   std::unique_ptr<Operator> next_;
   LevelSolver* next_level_ = nullptr;
   bool next_is_direct_ = false;
@@ -303,5 +305,6 @@ class LevelSolver : public Operator {
 // MatrixUtils::DropByValue (reference src/HYMLS_MatrixUtils.cpp:1011-1212); kind:
 // 0 RelDropDiag, 1 RelZeroDiag, 2 RelFullDiag
 Csr drop_by_value(const Csr& A, double tol, int kind);
+void drop_by_value(const Csr& A, double tol, int kind, Csr& R);   // into an existing matrix (arrays reused)
 
 }  // namespace hymls

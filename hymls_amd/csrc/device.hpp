@@ -136,7 +136,12 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
                       int32_t b0, int32_t nbc, const double* kval);
 // all big fronts of one tree level (device list of front ids, host copies for the grid sizes)
 // poff: device array (per listed front) of offsets into the partial-sum area of the workspace
-constexpr int SOLVE_KT = 1024;   // columns per workgroup tile of the big-front panel products
+// columns per workgroup tile of the big-front panel products: 1024, or 256 (HYMLS_MI_SOLVE_KT; more workgroups for the
+// fronts of a few thousand columns near the root of one large system)
+inline int solve_kt() {
+  static const int kt = (std::getenv("HYMLS_MI_SOLVE_KT") && std::atoi(std::getenv("HYMLS_MI_SOLVE_KT")) == 256) ? 256 : 1024;
+  return kt;
+}
 void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hfronts, const int64_t* poff,
                    int32_t count, double* x);
 void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const FrontD* hfronts, const int64_t* poff,

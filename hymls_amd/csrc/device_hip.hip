@@ -387,8 +387,15 @@ __device__ inline void block_absmax(const double* S, int64_t ld, int w, bool low
   atomicMax(acc, (unsigned long long)__double_as_longlong(m));
 }
 
+template <bool PROF>
 __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const int32_t* __restrict__ list, int32_t b0,
-                                                      const double* __restrict__ kval) {
+                                                      const double* __restrict__ kval, unsigned long long* __restrict__ prof) {
+  // PROF (HYMLS_MI_FACTOR_PROF): 100 MHz wall-clock ticks per phase, summed over the workgroups of the launch
+  long long t_prev = 0;
+  auto tick = [&](int phase) {
+    if (PROF) { __syncthreads(); if (threadIdx.x == 0) { const long long t = wall_clock64(); atomicAdd(&prof[phase], (unsigned long long)(t - t_prev)); t_prev = t; } }
+  };
+  if (PROF && threadIdx.x == 0) t_prev = wall_clock64();
   __shared__ double lds[STAGE_DOUBLES + 2 * GEMM_KB * 64];
   __shared__ int s_bad;
   __shared__ unsigned long long s_m0, s_ml, s_mu;
@@ -407,6 +414,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
   const int32_t* src = B.src + (int64_t)b * P.nent;
   for (int e = F.ent_begin + tid; e < F.ent_end; e += FT) A[P.ent_pos[e]] += P.ent_w[e] * kval[src[P.ent_id[e]]];
   __syncthreads();
+  tick(0);
   for (int ce = F.child_begin; ce < F.child_end; ce++) {
     const FrontD Cf = P.fronts[P.children[ce]];
     const int mc = Cf.w + Cf.ri + Cf.rs, rc = Cf.ri + Cf.rs;
@@ -418,6 +426,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     }
     __syncthreads();
   }
+  tick(1);
   double* fac = B.factor + (int64_t)b * P.factor_size;
   double* Lp = fac + F.lp_off;
   double* Q = fac + F.q_off;
@@ -511,6 +520,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
   if (s_bad && tid == 0) atomicOr(B.flag, s_bad);
   __threadfence_block();
   __syncthreads();
+  tick(2);
   if (r > 0) {
     // 4. U12 = L11^{-1} F12 in place (column blocks staged in LDS)
     {
@@ -528,6 +538,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
         __syncthreads();
       }
     }
+    tick(3);
     // 5. L21 = F21 U11^{-1} in place (row blocks staged in LDS)
     {
       const int rb = max(1, STAGE_DOUBLES / w);
@@ -544,8 +555,10 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
         __syncthreads();
       }
     }
+    tick(4);
     // 6. Schur update F22 -= L21 U12
     wg_gemm<true>(A + w + (int64_t)m * w, m, A + w, m, A + (int64_t)m * w, m, r, r, w, lds + STAGE_DOUBLES);
+    tick(5);
     // 7. solve panels: PL = L21_int L11^{-1}, QU = U11^{-1} U12_int
     if (ri > 0) {
       for (int64_t t = tid; t < (int64_t)ri * w; t += FT) {
@@ -561,6 +574,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
         Q[i + (int64_t)w * j] = s;
       }
     }
+    tick(6);
     // 8. root fronts: add the update to the separator block
     if (F.parent < 0 && rs > 0) {
       __syncthreads();
@@ -572,6 +586,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       }
     }
   }
+  tick(7);
 }
 
 void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, int32_t b0, int32_t nbc,
@@ -582,8 +597,28 @@ void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t 
     BatchD B2 = B;
     B2.scratch = B.scratch + (int64_t)s0 * P.scratch_size;
     if (B.sblock) B2.sblock = B.sblock + (int64_t)s0 * P.nS * P.nS;
-    hipLaunchKernelGGL(k_factor_level, dim3(count, ns), dim3(FT), 0, g_stream, P, B2, list, b0 + s0, kval);
+    static const bool prof = std::getenv("HYMLS_MI_FACTOR_PROF") != nullptr;
+    if (!prof) {
+      hipLaunchKernelGGL(k_factor_level<false>, dim3(count, ns), dim3(FT), 0, g_stream, P, B2, list, b0 + s0, kval, (unsigned long long*)nullptr);
+      launch_check();
+      continue;
+    }
+    // development aid: per-phase ticks of this launch on stderr (synchronises)
+    unsigned long long* dprof = (unsigned long long*)alloc(8 * sizeof(unsigned long long));
+    zero(dprof, 8 * sizeof(unsigned long long));
+    timer_start(15);
+    hipLaunchKernelGGL(k_factor_level<true>, dim3(count, ns), dim3(FT), 0, g_stream, P, B2, list, b0 + s0, kval, dprof);
     launch_check();
+    const double sec = timer_stop(15);
+    unsigned long long h[8];
+    d2h(h, dprof, sizeof h);
+    free(dprof);
+    double tot = 0;
+    for (int q = 0; q < 8; q++) tot += (double)h[q];
+    std::fprintf(stderr, "[hymls_mi] k_factor_level: %d fronts x %d members, %.3f ms; share of workgroup time: entries %.1f%% extend-add %.1f%% LU+inverses %.1f%% "
+                         "U12 %.1f%% L21 %.1f%% Schur GEMM %.1f%% solve panels %.1f%% root update %.1f%%; mean workgroup %.1f us\n",
+                 count, ns, 1e3 * sec, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot,
+                 100 * h[6] / tot, 100 * h[7] / tot, tot / 100.0 / ((double)count * ns));
   }
 }
 
@@ -923,16 +958,16 @@ __global__ void __launch_bounds__(256) k_asm_big(PlanD P, BatchD B, const int32_
   B.swork[(int64_t)b * B.swork_stride + F.a_off + j] = v;
 }
 // Panel-times-vector products of the big fronts.  A workgroup (4 waves) owns a tile of 64 rows x
-// KT = 1024 columns; lane = row (every panel load is a coalesced 512-byte line), wave g takes 256
+// KT = 1024 (or 256) columns; lane = row (every panel load is a coalesced 512-byte line), wave g takes 256
 // of the columns, 8 independent loads in flight per lane.  Partial sums go to the workspace and a
 // finalize kernel adds the column tiles in a fixed order (bitwise reproducible).  Tiles that lie
 // entirely outside the triangular part of the pivot block are skipped by both kernels.
-constexpr int KT = 1024;
 __device__ inline double wave4_reduce_store(double v, double (*red)[64], int g, int lane) {
   red[g][lane] = v;
   __syncthreads();
   return red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
+template <int KT>
 __global__ void __launch_bounds__(256) k_panel_fwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
                                                     int32_t count) {
   __shared__ double red[4][64];
@@ -949,7 +984,7 @@ __global__ void __launch_bounds__(256) k_panel_fwd(PlanD P, BatchD B, const int3
   const double* __restrict__ a = B.swork + (int64_t)b * B.swork_stride + F.a_off;
   const double* __restrict__ Lp = B.factor + (int64_t)b * P.factor_size + F.lp_off + (i < rows ? i : 0);
   const int krow = i < rows ? (i < w ? i : w) : 0;    // this row uses columns k < krow
-  const int kb = c0k + g * 256, ke = min(min(kb + 256, kchunk), c0k + KT);
+  const int kb = c0k + g * (KT / 4), ke = min(min(kb + KT / 4, kchunk), c0k + KT);
   double acc[8];
 #pragma unroll
   for (int u = 0; u < 8; u++) acc[u] = 0.0;
@@ -966,6 +1001,7 @@ __global__ void __launch_bounds__(256) k_panel_fwd(PlanD P, BatchD B, const int3
   const double sum = wave4_reduce_store(v, red, g, lane);
   if (g == 0 && i < rows) B.swork[(int64_t)b * B.swork_stride + P.asm_rows + poff[q] + (int64_t)blockIdx.y * rows + i] = sum;
 }
+template <int KT>
 __global__ void __launch_bounds__(256) k_final_fwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
                                                     int32_t count, double* __restrict__ x) {
   const int q = blockIdx.y % count, b = blockIdx.y / count;
@@ -989,13 +1025,20 @@ void solve_fwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const F
   int maxrows = 0, maxw = 0;
   for (int q = 0; q < count; q++) { maxrows = std::max(maxrows, hf[q].w + hf[q].ri); maxw = std::max(maxw, hf[q].w); }
   hipLaunchKernelGGL(k_asm_big, dim3((maxrows + 255) / 256, count, B.nb), dim3(256), 0, g_stream, P, B, list, x); launch_check();
-  hipLaunchKernelGGL(k_panel_fwd, dim3((maxrows + 63) / 64, (maxw + KT - 1) / KT, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count);
-  launch_check();
-  hipLaunchKernelGGL(k_final_fwd, dim3((maxrows + 255) / 256, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+  if (solve_kt() == 256) {
+    hipLaunchKernelGGL(k_panel_fwd<256>, dim3((maxrows + 63) / 64, (maxw + 255) / 256, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count);
+    launch_check();
+    hipLaunchKernelGGL(k_final_fwd<256>, dim3((maxrows + 255) / 256, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+  } else {
+    hipLaunchKernelGGL(k_panel_fwd<1024>, dim3((maxrows + 63) / 64, (maxw + 1023) / 1024, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count);
+    launch_check();
+    hipLaunchKernelGGL(k_final_fwd<1024>, dim3((maxrows + 255) / 256, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+  }
   launch_check();
 }
 // backward: x_s = U^{-1} y_s - (U^{-1} U12) x_ancestors; column tiles [0, ctU) run over the upper
 // triangle of the pivot block, the following ones over the U-side panel
+template <int KT>
 __global__ void __launch_bounds__(256) k_panel_bwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
                                                     int32_t count, const double* __restrict__ x) {
   __shared__ double red[4][64];
@@ -1018,7 +1061,7 @@ __global__ void __launch_bounds__(256) k_panel_bwd(PlanD P, BatchD B, const int3
     const int64_t ld = w + ri;
     const double* __restrict__ Lp = fac + F.lp_off + (i < w ? i : 0);
     const double* __restrict__ y = xb + F.c0;
-    const int kb = max(c0k + g * 256, (r0 / 8) * 8), ke = min(c0k + g * 256 + 256, w);
+    const int kb = max(c0k + g * (KT / 4), (r0 / 8) * 8), ke = min(c0k + g * (KT / 4) + KT / 4, w);
     int k = kb;
     for (; k + 7 < ke; k += 8) {
       double l[8], t[8];
@@ -1033,7 +1076,7 @@ __global__ void __launch_bounds__(256) k_panel_bwd(PlanD P, BatchD B, const int3
     if (c0k >= ri) return;
     const double* __restrict__ Q = fac + F.q_off + (i < w ? i : 0);
     const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
-    const int kb = c0k + g * 256, ke = min(kb + 256, ri);
+    const int kb = c0k + g * (KT / 4), ke = min(kb + KT / 4, ri);
     int k = kb;
     for (; k + 7 < ke; k += 8) {
       double l[8], t[8];
@@ -1048,6 +1091,7 @@ __global__ void __launch_bounds__(256) k_panel_bwd(PlanD P, BatchD B, const int3
   const double sum = wave4_reduce_store(v, red, g, lane);
   if (g == 0 && i < w) B.swork[(int64_t)b * B.swork_stride + P.asm_rows + poff[q] + (int64_t)ct * w + i] = sum;
 }
+template <int KT>
 __global__ void __launch_bounds__(256) k_final_bwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
                                                     int32_t count, double* __restrict__ x) {
   const int q = blockIdx.y % count, b = blockIdx.y / count;
@@ -1067,14 +1111,21 @@ void solve_bwd_big(const PlanD& P, const BatchD& B, const int32_t* list, const F
                    double* x) {
   if (count <= 0 || B.nb <= 0) return;
   if ((int64_t)count * B.nb > 65535) throw Error(-3, "too many (front, member) pairs for the big-front path");
+  const int KT = solve_kt();
   int maxw = 0, maxct = 0;
   for (int q = 0; q < count; q++) {
     maxw = std::max(maxw, hf[q].w);
     maxct = std::max(maxct, (hf[q].w + KT - 1) / KT + (hf[q].ri + KT - 1) / KT);
   }
-  hipLaunchKernelGGL(k_panel_bwd, dim3((maxw + 63) / 64, maxct, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
-  launch_check();
-  hipLaunchKernelGGL(k_final_bwd, dim3((maxw + 255) / 256, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+  if (KT == 256) {
+    hipLaunchKernelGGL(k_panel_bwd<256>, dim3((maxw + 63) / 64, maxct, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+    launch_check();
+    hipLaunchKernelGGL(k_final_bwd<256>, dim3((maxw + 255) / 256, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+  } else {
+    hipLaunchKernelGGL(k_panel_bwd<1024>, dim3((maxw + 63) / 64, maxct, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+    launch_check();
+    hipLaunchKernelGGL(k_final_bwd<1024>, dim3((maxw + 255) / 256, count * B.nb), dim3(256), 0, g_stream, P, B, list, poff, count, x);
+  }
   launch_check();
 }
 

@@ -160,7 +160,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
       int64_t off = 0;
       for (int s : L) {
         h_big_fronts.back().push_back(fd[s]);
-        const int64_t w = fd[s].w, ri = fd[s].ri, kt = dev::SOLVE_KT;
+        const int64_t w = fd[s].w, ri = fd[s].ri, kt = dev::solve_kt();
         const int64_t ctw = (w + kt - 1) / kt, ctr = (ri + kt - 1) / kt;
         poff.push_back(off);
         off += std::max(ctw * (w + ri), (ctw + ctr) * w);

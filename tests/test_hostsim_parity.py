@@ -212,17 +212,6 @@ def test_reference_driven_cavity_2d_64(hostsim_lib):
     cavity2d_case(hostsim_lib, "re1000", "Cartesian", 2, 250, grid=64)
 
 
-def test_io_fusion_option(hostsim_lib, monkeypatch):
-    """HYMLS_MI_IO_FUSION=1: entry gather, A12 x2, the x1 update and the exit scatter fused into the interior solves"""
-    A, tv = problem("Stokes-C", 16)
-    prm = xml_params("Stokes-C", 16, 8, 1, partitioner="Skew Cartesian")
-    b = np.random.default_rng(13).uniform(-1, 1, A.shape[0])
-    x_plain = product_prec(A, tv, prm, hostsim_lib).ApplyInverse(b)
-    monkeypatch.setenv("HYMLS_MI_IO_FUSION", "1")
-    x_fused = product_prec(A, tv, prm, hostsim_lib).ApplyInverse(b)
-    assert rel_diff(x_fused, x_plain) < 1e-13
-
-
 def test_tiled_separator_block_apply(hostsim_lib, monkeypatch):
     """large separator blocks are applied in 64-row tiles (one wave each); force the tiling on small blocks"""
     A, tv = problem("Stokes-C", 16)

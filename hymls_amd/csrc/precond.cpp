@@ -131,6 +131,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
     dplan.max_solve_rows = msr;
   }
   for (auto& L : plan.levels) d_lists.push_back(keep(dev::upload(L)));
+  for (auto& L : plan.flevels) d_flists.push_back(keep(dev::upload(L)));
   const int64_t per = plan.scratch_size + (with_sblock ? (int64_t)plan.nS * plan.nS : 0);
   chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nb, budget / std::max<int64_t>(per, 1)));
   batch.nb = nb;
@@ -145,13 +146,17 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   batch.flag = (int32_t*)keep(dev::alloc(sizeof(int32_t)));
   dev::zero(batch.flag, sizeof(int32_t));
   h_fronts = fd;
-  bool any_big = false;
+  bool any_big = false, any_wide = false;
   for (auto& L : plan.big_levels) any_big |= !L.empty();
+  for (auto& L : plan.fwide_levels) any_wide |= !L.empty();
   batch.tmp = nullptr; batch.tmp_stride = 0; batch.swork = nullptr; batch.swork_stride = 0;
-  if (any_big) {
+  if (any_wide) {
+    // pivot-piece workspace of the multi-workgroup factorisation
     const int64_t np = (plan.max_w + dev::PIECE - 1) / dev::PIECE;
     batch.tmp_stride = np * 2 * dev::PIECE * dev::PIECE + 2LL * plan.max_w * dev::PIECE;
     tmp_need_ = (int64_t)chunk * batch.tmp_stride;
+  }
+  if (any_big) {
     int64_t part_max = 0;
     for (auto& L : plan.big_levels) {
       d_big_lists.push_back(keep(dev::upload(L)));
@@ -189,9 +194,9 @@ void BatchedLU::bind_scratch() {
 void BatchedLU::factor_chunk(const double* kval, int32_t b0, int32_t nbc) {
   bind_scratch();
   if (batch.sblock) dev::sblock_init(dplan, batch, b0, nbc, kval);
-  for (size_t l = 0; l < plan.levels.size(); l++) {
-    dev::factor_level(dplan, batch, d_lists[l], (int32_t)plan.levels[l].size(), b0, nbc, kval);
-    for (int s : plan.big_levels[l]) {
+  for (size_t l = 0; l < plan.flevels.size(); l++) {
+    dev::factor_level(dplan, batch, d_flists[l], (int32_t)plan.flevels[l].size(), b0, nbc, kval);
+    for (int s : plan.fwide_levels[l]) {
       auto k = kids_of(s);
       dev::factor_big_front(dplan, batch, h_fronts[s], k.data(), (int32_t)k.size(), b0, nbc, kval);
     }

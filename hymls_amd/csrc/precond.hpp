@@ -31,7 +31,8 @@ struct BatchedLU {
   // device
   dev::PlanD dplan{};
   dev::BatchD batch{};
-  std::vector<int32_t*> d_lists;  // per tree level
+  std::vector<int32_t*> d_lists;  // per tree level (solve)
+  std::vector<int32_t*> d_flists; // per tree level (factorisation: the fronts one workgroup factors)
   std::vector<dev::FrontD> h_fronts;  // host copies (grid setup of the big-front kernels)
   std::vector<int32_t*> d_big_lists;  // per tree level: ids of the big fronts
   std::vector<std::vector<dev::FrontD>> h_big_fronts;

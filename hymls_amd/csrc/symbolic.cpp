@@ -367,6 +367,8 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   }
   P.levels.assign(nf ? maxlev + 1 : 0, ivec());
   P.big_levels.assign(nf ? maxlev + 1 : 0, ivec());
+  P.flevels.assign(nf ? maxlev + 1 : 0, ivec());
+  P.fwide_levels.assign(nf ? maxlev + 1 : 0, ivec());
   // --- index lists, offsets
   int64_t foff = 0, fac = 0;
   int32_t coff = 0, aoff = 0;
@@ -392,6 +394,12 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
       static const double big_flops = std::getenv("HYMLS_MI_BIG_FLOPS") ? std::atof(std::getenv("HYMLS_MI_BIG_FLOPS")) : 2.5e7;
       F.big = r * r * F.w > big_flops || m > 2048 || (int64_t)(F.w + F.ri) * F.w > big_panel_entries || F.w > max_width;
       (F.big ? P.big_levels : P.levels)[F.level].push_back(s);
+      // factorisation: a Schur update of a few MFLOP already takes one workgroup milliseconds (measured: the root front
+      // of a level-1 subdomain, 546 x 546 x 49, 4.4 ms in k_factor_level -- 41 % in its VALU GEMM, 21 % extend-add); the
+      // grid-wide kernels (MFMA GEMM batched over the members) do the same work for all members of a chunk in one go
+      static const double wide_flops = std::getenv("HYMLS_MI_WIDE_FACTOR_FLOPS") ? std::atof(std::getenv("HYMLS_MI_WIDE_FACTOR_FLOPS")) : 3e6;
+      F.wide = F.big || r * r * F.w > wide_flops;
+      (F.wide ? P.fwide_levels : P.flevels)[F.level].push_back(s);
     }
     P.max_solve_rows = std::max<int32_t>(P.max_solve_rows, F.w + F.ri);
     P.nnz_factor += (int64_t)F.w * F.w + 2LL * F.w * F.ri;

@@ -47,7 +47,8 @@ struct Front {
   int32_t lf_off = 0;         // offset of its assembled vector inside its tree level's LDS region (fused solve)
   int32_t ent_begin = 0, ent_end = 0;  // matrix entries assembled into this front
   int32_t child_begin = 0, child_end = 0;  // into ClassPlan::children
-  bool big = false;            // processed by the multi-workgroup kernels
+  bool big = false;            // factored AND solved by the multi-workgroup kernels
+  bool wide = false;           // factored by the multi-workgroup kernels (big, or a Schur update too large for one workgroup)
   int32_t m() const { return w + ri + rs; }
 };
 
@@ -63,6 +64,9 @@ struct ClassPlan {
   ivec children;              // child front ids grouped per front
   std::vector<ivec> levels;   // front ids per tree level (leaves = 0): fronts handled by one workgroup each
   std::vector<ivec> big_levels;  // per tree level: fronts spread over many workgroups
+  // scheduling of the factorisation only: fronts one workgroup factors / fronts the multi-workgroup kernels factor
+  // (the same partition of the fronts as levels / big_levels, with more fronts on the multi-workgroup side)
+  std::vector<ivec> flevels, fwide_levels;
   int32_t max_w = 0;
   int32_t asm_rows = 0;       // sum over fronts of (w + ri)
   ivec asm_ptr, asm_src;      // per assembled row: contribution entries (index into the contrib array) to add

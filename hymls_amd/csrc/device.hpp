@@ -124,8 +124,9 @@ void pull_sum_blocks(int64_t blen, int32_t nblk, const int64_t* ptr, const int64
 
 // ---- multifrontal numeric factorisation, one tree level, fronts [first, first+count) of
 // `list` (front ids), batch members [b0, b0+nbc) mapped to scratch slots 0..nbc-1
+// max_w: widest pivot block among the listed fronts (selects the LDS size of the kernel)
 void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count,
-                  int32_t b0, int32_t nbc, const double* kval);
+                  int32_t b0, int32_t nbc, const double* kval, int32_t max_w);
 // separator block: S = weighted A22 entries (call before the tree), per batch member
 void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const double* kval);
 

@@ -315,7 +315,6 @@ void pull_sum_blocks(int64_t blen, int32_t nblk, const int64_t* ptr, const int64
 // ------------------------------------------------------------------ multifrontal factorisation
 constexpr int FT = 256;          // threads per front workgroup
 constexpr int GEMM_KB = 16;
-constexpr int STAGE_DOUBLES = 4096;  // 32 KB staging buffer for the in-place panel products
 
 // C(MxN) = beta*C - or + A(MxK) B(KxN), column-major, executed by the whole workgroup.
 // 64x64 tile per pass, 4x4 micro-tile per thread, K staged through LDS in slabs of GEMM_KB.
@@ -387,7 +386,9 @@ __device__ inline void block_absmax(const double* S, int64_t ld, int w, bool low
   atomicMax(acc, (unsigned long long)__double_as_longlong(m));
 }
 
-template <bool PROF>
+// LD: doubles of LDS (pivot block + work vector, then staging of the panel products, then the GEMM slabs: the three
+// uses follow each other).  3072 (24 KiB, 6 workgroups per CU) for pivot blocks up to 54 wide, else 6144 (up to 77).
+template <bool PROF, int LD>
 __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const int32_t* __restrict__ list, int32_t b0,
                                                       const double* __restrict__ kval, unsigned long long* __restrict__ prof) {
   // PROF (HYMLS_MI_FACTOR_PROF): 100 MHz wall-clock ticks per phase, summed over the workgroups of the launch
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     if (PROF) { __syncthreads(); if (threadIdx.x == 0) { const long long t = wall_clock64(); atomicAdd(&prof[phase], (unsigned long long)(t - t_prev)); t_prev = t; } }
   };
   if (PROF && threadIdx.x == 0) t_prev = wall_clock64();
-  __shared__ double lds[STAGE_DOUBLES + 2 * GEMM_KB * 64];
+  __shared__ double lds[LD];
   __shared__ int s_bad;
   __shared__ unsigned long long s_m0, s_ml, s_mu;
   const int tid = threadIdx.x;
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
   double* Lp = fac + F.lp_off;
   double* Q = fac + F.q_off;
   const int64_t ld = w + ri;
-  if (w * w + w <= STAGE_DOUBLES + 2 * GEMM_KB * 64) {
+  if (w * w + w <= LD) {
     // 2+3 (LDS path): LU of the pivot block and in-place triangular inverses inside LDS
     double* S = lds;
     double* xv = lds + w * w;
@@ -461,9 +462,14 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       for (int i = j + 1 + tid; i < w; i += FT) xv[i] = S[i + w * j];
       __syncthreads();
       for (int i = j + 1 + tid; i < w; i += FT) {
-        double sum = xv[i];
-        for (int k = j + 1; k < i; k++) sum += S[i + w * k] * xv[k];
-        S[i + w * j] = -sum;
+        double s0 = xv[i], s1 = 0.0, s2 = 0.0, s3 = 0.0;    // four chains instead of one dependent chain of length i - j
+        int k = j + 1;
+        for (; k + 3 < i; k += 4) {
+          s0 += S[i + w * k] * xv[k]; s1 += S[i + w * (k + 1)] * xv[k + 1];
+          s2 += S[i + w * (k + 2)] * xv[k + 2]; s3 += S[i + w * (k + 3)] * xv[k + 3];
+        }
+        for (; k < i; k++) s0 += S[i + w * k] * xv[k];
+        S[i + w * j] = -((s0 + s1) + (s2 + s3));
       }
       __syncthreads();
     }
@@ -472,9 +478,14 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       const double d = 1.0 / S[j + w * j];
       __syncthreads();
       for (int i = tid; i < j; i += FT) {
-        double sum = 0.0;
-        for (int k = i; k < j; k++) sum += S[i + w * k] * xv[k];
-        S[i + w * j] = -sum * d;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = i;
+        for (; k + 3 < j; k += 4) {
+          s0 += S[i + w * k] * xv[k]; s1 += S[i + w * (k + 1)] * xv[k + 1];
+          s2 += S[i + w * (k + 2)] * xv[k + 2]; s3 += S[i + w * (k + 3)] * xv[k + 3];
+        }
+        for (; k < j; k++) s0 += S[i + w * k] * xv[k];
+        S[i + w * j] = -((s0 + s1) + (s2 + s3)) * d;
       }
       if (tid == 0) S[j + w * j] = d;
       __syncthreads();
@@ -524,16 +535,21 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
   if (r > 0) {
     // 4. U12 = L11^{-1} F12 in place (column blocks staged in LDS)
     {
-      const int cb = max(1, STAGE_DOUBLES / w);
+      const int cb = max(1, LD / w);
       for (int j0 = 0; j0 < r; j0 += cb) {
         const int nc = min(cb, r - j0);
         for (int t = tid; t < w * nc; t += FT) lds[t] = A[(t % w) + (int64_t)m * (w + j0 + t / w)];
         __syncthreads();
         for (int t = tid; t < w * nc; t += FT) {
           const int i = t % w, j = t / w;
-          double s = lds[i + w * j];
-          for (int k = 0; k < i; k++) s += Lp[i + ld * k] * lds[k + w * j];
-          A[i + (int64_t)m * (w + j0 + j)] = s;
+          double s0 = lds[i + w * j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+          int k = 0;
+          for (; k + 3 < i; k += 4) {
+            s0 += Lp[i + ld * k] * lds[k + w * j]; s1 += Lp[i + ld * (k + 1)] * lds[k + 1 + w * j];
+            s2 += Lp[i + ld * (k + 2)] * lds[k + 2 + w * j]; s3 += Lp[i + ld * (k + 3)] * lds[k + 3 + w * j];
+          }
+          for (; k < i; k++) s0 += Lp[i + ld * k] * lds[k + w * j];
+          A[i + (int64_t)m * (w + j0 + j)] = (s0 + s1) + (s2 + s3);
         }
         __syncthreads();
       }
@@ -541,37 +557,52 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     tick(3);
     // 5. L21 = F21 U11^{-1} in place (row blocks staged in LDS)
     {
-      const int rb = max(1, STAGE_DOUBLES / w);
+      const int rb = max(1, LD / w);
       for (int i0 = 0; i0 < r; i0 += rb) {
         const int nr = min(rb, r - i0);
         for (int t = tid; t < nr * w; t += FT) lds[t] = A[(w + i0 + t % nr) + (int64_t)m * (t / nr)];
         __syncthreads();
         for (int t = tid; t < nr * w; t += FT) {
           const int i = t % nr, j = t / nr;
-          double s = 0.0;
-          for (int k = 0; k <= j; k++) s += lds[i + nr * k] * Lp[k + ld * j];
-          A[(w + i0 + i) + (int64_t)m * j] = s;
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+          int k = 0;
+          for (; k + 3 <= j; k += 4) {
+            s0 += lds[i + nr * k] * Lp[k + ld * j]; s1 += lds[i + nr * (k + 1)] * Lp[k + 1 + ld * j];
+            s2 += lds[i + nr * (k + 2)] * Lp[k + 2 + ld * j]; s3 += lds[i + nr * (k + 3)] * Lp[k + 3 + ld * j];
+          }
+          for (; k <= j; k++) s0 += lds[i + nr * k] * Lp[k + ld * j];
+          A[(w + i0 + i) + (int64_t)m * j] = (s0 + s1) + (s2 + s3);
         }
         __syncthreads();
       }
     }
     tick(4);
     // 6. Schur update F22 -= L21 U12
-    wg_gemm<true>(A + w + (int64_t)m * w, m, A + w, m, A + (int64_t)m * w, m, r, r, w, lds + STAGE_DOUBLES);
+    wg_gemm<true>(A + w + (int64_t)m * w, m, A + w, m, A + (int64_t)m * w, m, r, r, w, lds);   // (2 x 16 x 64 doubles <= LD)
     tick(5);
     // 7. solve panels: PL = L21_int L11^{-1}, QU = U11^{-1} U12_int
     if (ri > 0) {
       for (int64_t t = tid; t < (int64_t)ri * w; t += FT) {
         const int i = (int)(t % ri), k = (int)(t / ri);
-        double s = A[(w + i) + (int64_t)m * k];                  // unit diagonal of L11^{-1}
-        for (int j = k + 1; j < w; j++) s += A[(w + i) + (int64_t)m * j] * Lp[j + ld * k];
-        Lp[(w + i) + ld * k] = s;
+        double s0 = A[(w + i) + (int64_t)m * k] /* unit diagonal of L11^{-1} */, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = k + 1;
+        for (; j + 3 < w; j += 4) {
+          s0 += A[(w + i) + (int64_t)m * j] * Lp[j + ld * k]; s1 += A[(w + i) + (int64_t)m * (j + 1)] * Lp[j + 1 + ld * k];
+          s2 += A[(w + i) + (int64_t)m * (j + 2)] * Lp[j + 2 + ld * k]; s3 += A[(w + i) + (int64_t)m * (j + 3)] * Lp[j + 3 + ld * k];
+        }
+        for (; j < w; j++) s0 += A[(w + i) + (int64_t)m * j] * Lp[j + ld * k];
+        Lp[(w + i) + ld * k] = (s0 + s1) + (s2 + s3);
       }
       for (int64_t t = tid; t < (int64_t)w * ri; t += FT) {
         const int i = (int)(t % w), j = (int)(t / w);
-        double s = 0.0;
-        for (int k = i; k < w; k++) s += Lp[i + ld * k] * A[k + (int64_t)m * (w + j)];
-        Q[i + (int64_t)w * j] = s;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = i;
+        for (; k + 3 < w; k += 4) {
+          s0 += Lp[i + ld * k] * A[k + (int64_t)m * (w + j)]; s1 += Lp[i + ld * (k + 1)] * A[k + 1 + (int64_t)m * (w + j)];
+          s2 += Lp[i + ld * (k + 2)] * A[k + 2 + (int64_t)m * (w + j)]; s3 += Lp[i + ld * (k + 3)] * A[k + 3 + (int64_t)m * (w + j)];
+        }
+        for (; k < w; k++) s0 += Lp[i + ld * k] * A[k + (int64_t)m * (w + j)];
+        Q[i + (int64_t)w * j] = (s0 + s1) + (s2 + s3);
       }
     }
     tick(6);
@@ -590,7 +621,8 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
 }
 
 void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, int32_t b0, int32_t nbc,
-                  const double* kval) {
+                  const double* kval, int32_t max_w) {
+  const bool small = max_w * max_w + max_w <= 3072;
   if (count <= 0 || nbc <= 0) return;
   for (int s0 = 0; s0 < nbc; s0 += 65535) {
     const int ns = std::min(65535, nbc - s0);
@@ -599,7 +631,8 @@ void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t 
     if (B.sblock) B2.sblock = B.sblock + (int64_t)s0 * P.nS * P.nS;
     static const bool prof = std::getenv("HYMLS_MI_FACTOR_PROF") != nullptr;
     if (!prof) {
-      hipLaunchKernelGGL(k_factor_level<false>, dim3(count, ns), dim3(FT), 0, g_stream, P, B2, list, b0 + s0, kval, (unsigned long long*)nullptr);
+      if (small) hipLaunchKernelGGL((k_factor_level<false, 3072>), dim3(count, ns), dim3(FT), 0, g_stream, P, B2, list, b0 + s0, kval, (unsigned long long*)nullptr);
+      else hipLaunchKernelGGL((k_factor_level<false, 6144>), dim3(count, ns), dim3(FT), 0, g_stream, P, B2, list, b0 + s0, kval, (unsigned long long*)nullptr);
       launch_check();
       continue;
     }
@@ -607,7 +640,8 @@ void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t 
     unsigned long long* dprof = (unsigned long long*)alloc(8 * sizeof(unsigned long long));
     zero(dprof, 8 * sizeof(unsigned long long));
     timer_start(15);
-    hipLaunchKernelGGL(k_factor_level<true>, dim3(count, ns), dim3(FT), 0, g_stream, P, B2, list, b0 + s0, kval, dprof);
+    if (small) hipLaunchKernelGGL((k_factor_level<true, 3072>), dim3(count, ns), dim3(FT), 0, g_stream, P, B2, list, b0 + s0, kval, dprof);
+    else hipLaunchKernelGGL((k_factor_level<true, 6144>), dim3(count, ns), dim3(FT), 0, g_stream, P, B2, list, b0 + s0, kval, dprof);
     launch_check();
     const double sec = timer_stop(15);
     unsigned long long h[8];
@@ -717,9 +751,14 @@ __global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64
     for (int i = j + 1 + tid; i < w; i += FT) xv[i] = S[i + w * j];
     __syncthreads();
     for (int i = j + 1 + tid; i < w; i += FT) {
-      double sum = xv[i];                                   // unit diagonal of X
-      for (int k = j + 1; k < i; k++) sum += S[i + w * k] * xv[k];
-      S[i + w * j] = -sum;
+      double s0 = xv[i] /* unit diagonal of X */, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = j + 1;
+      for (; k + 3 < i; k += 4) {
+        s0 += S[i + w * k] * xv[k]; s1 += S[i + w * (k + 1)] * xv[k + 1];
+        s2 += S[i + w * (k + 2)] * xv[k + 2]; s3 += S[i + w * (k + 3)] * xv[k + 3];
+      }
+      for (; k < i; k++) s0 += S[i + w * k] * xv[k];
+      S[i + w * j] = -((s0 + s1) + (s2 + s3));
     }
     __syncthreads();
   }
@@ -730,9 +769,14 @@ __global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64
     const double d = 1.0 / S[j + w * j];
     __syncthreads();
     for (int i = tid; i < j; i += FT) {
-      double sum = 0.0;
-      for (int k = i; k < j; k++) sum += S[i + w * k] * xv[k];
-      S[i + w * j] = -sum * d;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = i;
+      for (; k + 3 < j; k += 4) {
+        s0 += S[i + w * k] * xv[k]; s1 += S[i + w * (k + 1)] * xv[k + 1];
+        s2 += S[i + w * (k + 2)] * xv[k + 2]; s3 += S[i + w * (k + 3)] * xv[k + 3];
+      }
+      for (; k < j; k++) s0 += S[i + w * k] * xv[k];
+      S[i + w * j] = -((s0 + s1) + (s2 + s3)) * d;
     }
     if (tid == 0) S[j + w * j] = d;
     __syncthreads();
@@ -757,9 +801,14 @@ __global__ void __launch_bounds__(256) k_big_trmm_u(double* __restrict__ A0, int
   __syncthreads();
   for (int t = tid; t < w * nc; t += 256) {
     const int i = t % w, j = t / w;
-    double s = st[i + w * j];
-    for (int k = 0; k < i; k++) s += Lf[i + (int64_t)w * k] * st[k + w * j];
-    A[i + ld * (w + j0 + j)] = s;
+    double s0 = st[i + w * j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 3 < i; k += 4) {
+      s0 += Lf[i + (int64_t)w * k] * st[k + w * j]; s1 += Lf[i + (int64_t)w * (k + 1)] * st[k + 1 + w * j];
+      s2 += Lf[i + (int64_t)w * (k + 2)] * st[k + 2 + w * j]; s3 += Lf[i + (int64_t)w * (k + 3)] * st[k + 3 + w * j];
+    }
+    for (; k < i; k++) s0 += Lf[i + (int64_t)w * k] * st[k + w * j];
+    A[i + ld * (w + j0 + j)] = (s0 + s1) + (s2 + s3);
   }
 }
 // column panel below a pivot piece: L21 = F21 U^{-1} in place, one workgroup per 8 rows
@@ -774,9 +823,14 @@ __global__ void __launch_bounds__(256) k_big_trmm_l(double* __restrict__ A0, int
   __syncthreads();
   for (int t = tid; t < nr * w; t += 256) {
     const int i = t % nr, j = t / nr;
-    double s = 0.0;
-    for (int k = 0; k <= j; k++) s += st[i + nr * k] * Uf[k + (int64_t)w * j];
-    A[(w + i0 + i) + ld * j] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 3 <= j; k += 4) {
+      s0 += st[i + nr * k] * Uf[k + (int64_t)w * j]; s1 += st[i + nr * (k + 1)] * Uf[k + 1 + (int64_t)w * j];
+      s2 += st[i + nr * (k + 2)] * Uf[k + 2 + (int64_t)w * j]; s3 += st[i + nr * (k + 3)] * Uf[k + 3 + (int64_t)w * j];
+    }
+    for (; k <= j; k++) s0 += st[i + nr * k] * Uf[k + (int64_t)w * j];
+    A[(w + i0 + i) + ld * j] = (s0 + s1) + (s2 + s3);
   }
 }
 

@@ -195,7 +195,9 @@ void BatchedLU::factor_chunk(const double* kval, int32_t b0, int32_t nbc) {
   bind_scratch();
   if (batch.sblock) dev::sblock_init(dplan, batch, b0, nbc, kval);
   for (size_t l = 0; l < plan.flevels.size(); l++) {
-    dev::factor_level(dplan, batch, d_flists[l], (int32_t)plan.flevels[l].size(), b0, nbc, kval);
+    int32_t mw = 1;
+    for (int s : plan.flevels[l]) mw = std::max(mw, plan.fronts[s].w);
+    dev::factor_level(dplan, batch, d_flists[l], (int32_t)plan.flevels[l].size(), b0, nbc, kval, mw);
     for (int s : plan.fwide_levels[l]) {
       auto k = kids_of(s);
       dev::factor_big_front(dplan, batch, h_fronts[s], k.data(), (int32_t)k.size(), b0, nbc, kval);

@@ -155,7 +155,7 @@ static void sim_factor_front(const PlanD& P, const BatchD& B, const FrontD& F, i
 }
 
 void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, int32_t b0, int32_t nbc,
-                  const double* kval) {
+                  const double* kval, int32_t) {
   for (int slot = 0; slot < nbc; slot++)
     for (int q = 0; q < count; q++) sim_factor_front(P, B, P.fronts[list[q]], slot, b0 + slot, kval);
 }

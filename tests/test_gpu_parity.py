@@ -398,7 +398,8 @@ def test_unstable_pivot_free_factorisation_is_reported(gpu_lib):
     bad = (off + 1e-11 * sp.identity(A.shape[0])).tocsr()
     with pytest.raises(hymls_amd.HymlsError) as e:
         product_prec(bad, tv, prm, gpu_lib)
-    assert e.value.code == -4 and "unstable" in str(e.value)
+    # (element growth, or an exactly cancelled pivot further down the same front: both are reported as -4)
+    assert e.value.code == -4 and ("unstable" in str(e.value) or "pivot" in str(e.value))
     good = (off - 7.0 * sp.identity(A.shape[0])).tocsr()
     P = product_prec(good, tv, prm, gpu_lib)
     O = oracle_prec(good, tv, "Laplace", n, 4, 1)

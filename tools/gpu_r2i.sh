@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 O=gpurun_out/r2i
 mkdir -p $O
-timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "matches_oracle or multivector or compiled or lifecycle or unstable or bordered" > $O/gpu_tests.log 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "matches_oracle or compiled or unstable or bordered" > $O/gpu_tests.log 2>&1; rc=$?
 tail -5 $O/gpu_tests.log
 [ $rc -eq 0 ] || exit $rc
 for wf in 3e6 1e12 1.2e7; do

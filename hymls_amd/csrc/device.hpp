@@ -135,6 +135,9 @@ void sblock_init(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc, const
 constexpr int PIECE = 128;   // pivot pieces are factored and inverted inside LDS (128 x 128 x 8 B = 128 KiB)
 void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD* kids, int32_t nkids,
                       int32_t b0, int32_t nbc, const double* kval);
+// root front F (no interior ancestors): add its update matrix to the separator block of every slot.  One launch per
+// root, in a fixed order on the stream: the sum is formed in the same order on every Compute (bitwise reproducible)
+void root_update(const PlanD& P, const BatchD& B, const FrontD& F, int32_t nbc);
 // all big fronts of one tree level (device list of front ids, host copies for the grid sizes)
 // poff: device array (per listed front) of offsets into the partial-sum area of the workspace
 // columns per workgroup tile of the big-front panel products: 1024, or 256 (HYMLS_MI_SOLVE_KT; more workgroups for the

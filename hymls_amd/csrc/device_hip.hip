@@ -606,16 +606,8 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       }
     }
     tick(6);
-    // 8. root fronts: add the update to the separator block
-    if (F.parent < 0 && rs > 0) {
-      __syncthreads();
-      double* S = B.sblock + (int64_t)slot * P.nS * P.nS;
-      const int32_t* rel = P.rel + F.rel_off;
-      for (int64_t t = tid; t < (int64_t)rs * rs; t += FT) {
-        const int a = (int)(t % rs), bb = (int)(t / rs);
-        atomicAdd(&S[rel[ri + a] + (int64_t)P.nS * rel[ri + bb]], A[(w + ri + a) + (int64_t)m * (w + ri + bb)]);
-      }
-    }
+    // 8. (root fronts add their update to the separator block in root_update(), one launch per root in a fixed order:
+    //     concurrent atomic adds of several roots made Compute irreproducible in the last bits)
   }
   tick(7);
 }
@@ -930,7 +922,18 @@ __global__ void k_big_root_update(PlanD P, BatchD B, FrontD F) {
   const int64_t tot = (int64_t)rs * rs;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
     const int a = (int)(t % rs), bb = (int)(t / rs);
-    atomicAdd(&S[rel[ri + a] + (int64_t)P.nS * rel[ri + bb]], A[(w + ri + a) + (int64_t)m * (w + ri + bb)]);
+    S[rel[ri + a] + (int64_t)P.nS * rel[ri + bb]] += A[(w + ri + a) + (int64_t)m * (w + ri + bb)];   // (targets are unique within a root)
+  }
+}
+void root_update(const PlanD& P, const BatchD& B, const FrontD& F, int32_t nbc) {
+  if (nbc <= 0 || F.rs <= 0) return;
+  for (int s0 = 0; s0 < nbc; s0 += 65535) {
+    const int ns = std::min(65535, nbc - s0);
+    BatchD B2 = B;
+    B2.scratch = B.scratch + (int64_t)s0 * P.scratch_size;
+    B2.sblock = B.sblock + (int64_t)s0 * P.nS * P.nS;
+    hipLaunchKernelGGL(k_big_root_update, dim3(nblocks((int64_t)F.rs * F.rs, 256, 8192), ns), dim3(256), 0, g_stream, P, B2, F);
+    launch_check();
   }
 }
 
@@ -993,10 +996,7 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     gemm_f64<0, 0, 1>(slab + w, lds, sS, A0 + w, ld, sA, slab, lds, sS, ri, w, w, nbc);
     gemm_f64<0, 2, 0>(Qs, w, sS, slab, lds, sS, A0 + ld * w, ld, sA, w, ri, w, nbc);
   }
-  if (F.parent < 0 && rs > 0) {
-    hipLaunchKernelGGL(k_big_root_update, dim3(nblocks((int64_t)rs * rs, 256, 8192), nbc), dim3(256), 0, g_stream, P, B, F);
-    launch_check();
-  }
+  if (F.parent < 0 && rs > 0) root_update(P, B, F, nbc);
 }
 
 // ---- solves of the big fronts, all big fronts of one tree level per launch

@@ -203,6 +203,10 @@ void BatchedLU::factor_chunk(const double* kval, int32_t b0, int32_t nbc) {
       dev::factor_big_front(dplan, batch, h_fronts[s], k.data(), (int32_t)k.size(), b0, nbc, kval);
     }
   }
+  // the roots factored by k_factor_level add their updates to the separator block now, one after the other
+  if (batch.sblock)
+    for (size_t s = 0; s < plan.fronts.size(); s++)
+      if (!plan.fronts[s].wide && plan.fronts[s].parent < 0 && plan.fronts[s].rs > 0) dev::root_update(dplan, batch, h_fronts[s], nbc);
 }
 
 void BatchedLU::repack_chunk(int32_t b0, int32_t nbc) {

@@ -145,13 +145,19 @@ static void sim_factor_front(const PlanD& P, const BatchD& B, const FrontD& F, i
           for (int k = i + 1; k < w; k++) s -= Lk(i, k) * Q[k + (int64_t)w * j];
           Q[i + (int64_t)w * j] = s / Lk(i, i);
         }
-      if (F.parent < 0 && rs > 0) {
-        double* S = B.sblock + (int64_t)slot * P.nS * P.nS;
-        const int32_t* rel = P.rel + F.rel_off;
-        for (int bb = 0; bb < rs; bb++)
-          for (int a = 0; a < rs; a++) S[rel[ri + a] + (int64_t)P.nS * rel[ri + bb]] += A[(w + ri + a) + (int64_t)m * (w + ri + bb)];
-      }
+      (void)rs;   // (root fronts: root_update())
     }
+}
+
+void root_update(const PlanD& P, const BatchD& B, const FrontD& F, int32_t nbc) {
+  const int w = F.w, ri = F.ri, rs = F.rs, m = w + ri + rs;
+  const int32_t* rel = P.rel + F.rel_off;
+  for (int slot = 0; slot < nbc; slot++) {
+    const double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
+    double* S = B.sblock + (int64_t)slot * P.nS * P.nS;
+    for (int bb = 0; bb < rs; bb++)
+      for (int a = 0; a < rs; a++) S[rel[ri + a] + (int64_t)P.nS * rel[ri + bb]] += A[(w + ri + a) + (int64_t)m * (w + ri + bb)];
+  }
 }
 
 void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, int32_t b0, int32_t nbc,
@@ -162,6 +168,7 @@ void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t 
 void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const FrontD*, int32_t, int32_t b0, int32_t nbc,
                       const double* kval) {
   for (int slot = 0; slot < nbc; slot++) sim_factor_front(P, B, F, slot, b0 + slot, kval);
+  if (F.parent < 0 && F.rs > 0) root_update(P, B, F, nbc);   // (as the HIP launcher does)
 }
 
 static void sim_fwd_front(const PlanD& P, const BatchD& B, const FrontD& F, int b, double* x) {

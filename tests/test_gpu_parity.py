@@ -408,6 +408,24 @@ def test_unstable_pivot_free_factorisation_is_reported(gpu_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,sx,levels,cx,part", [("Stokes-C", 16, 8, 1, -1, "Skew Cartesian"), ("Stokes-C", 32, 4, 2, 2, "Skew Cartesian"),
+                                                  ("Laplace", 32, 4, 2, -1, "Cartesian")])
+def test_compute_is_bitwise_reproducible(gpu_lib, eq, n, sx, levels, cx, part):
+    """Compute twice (and on a second handle): the same bits in ApplyInverse.  The updates of several root fronts to
+    one separator block are added in a fixed order (they were concurrent atomic adds in round 1)."""
+    A, tv = problem(eq, n)
+    prm = xml_params(eq, n, sx, levels, cx=cx, partitioner=part)
+    P = product_prec(A, tv, prm, gpu_lib)
+    b = np.random.default_rng(13).uniform(-1, 1, A.shape[0])
+    x1 = P.ApplyInverse(b)
+    for _ in range(2):
+        P.Compute()
+        assert np.array_equal(P.ApplyInverse(b), x1)
+    Q = product_prec(A, tv, prm, gpu_lib)
+    assert np.array_equal(Q.ApplyInverse(b), x1)
+
+
+@pytest.mark.gpu
 def test_two_live_handles_alternate(gpu_lib):
     """every handle owns its device context (stream, arenas, profiling marks): two preconditioners alive at the same
     time, applied alternately, give exactly what each gives alone (reference: any number of Preconditioner objects)."""

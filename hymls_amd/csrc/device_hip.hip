@@ -614,7 +614,8 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
 
 void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, int32_t b0, int32_t nbc,
                   const double* kval, int32_t max_w) {
-  const bool small = max_w * max_w + max_w <= 3072;
+  static const bool force_big = std::getenv("HYMLS_MI_FACTOR_LDS") && std::atoi(std::getenv("HYMLS_MI_FACTOR_LDS")) > 3072;   // (A/B switch)
+  const bool small = !force_big && max_w * max_w + max_w <= 3072;
   if (count <= 0 || nbc <= 0) return;
   for (int s0 = 0; s0 < nbc; s0 += 65535) {
     const int ns = std::min(65535, nbc - s0);

@@ -11,7 +11,8 @@ import ctypes as C
 import os
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhymls_mi.so")
+# (HYMLS_MI_LIBRARY: another build of the same library, for A/B measurements)
+LIB_PATH = os.environ.get("HYMLS_MI_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhymls_mi.so")
 
 
 class HymlsError(RuntimeError):

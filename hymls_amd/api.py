@@ -25,7 +25,8 @@ class _Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "nx", "ny", "nz", "dim", "equations", "dof", "sx", "sy", "sz", "cx", "cy", "cz", "levels",
         "partitioner", "retain_nodes", "retain_pressures", "link_velocities", "link_retained",
-        "fix_pressure_level", "nfix")] + [("fix_gid", C.c_int32 * 4), ("variable_type", C.c_int32 * 8)]
+        "fix_pressure_level", "nfix")] + [("fix_gid", C.c_int32 * 4), ("variable_type", C.c_int32 * 8),
+                                         ("retain_xyz", C.c_int32 * 3), ("retain_at_level", C.c_int32 * 8)]
 
 
 _I32P = C.POINTER(C.c_int32)
@@ -309,6 +310,10 @@ class Preconditioner:
         p.levels = prec.get("Number of Levels", 1)
         p.partitioner = _PART[prec.get("Partitioner", "Cartesian")]
         p.retain_nodes = prec.get("Retain Nodes", -1)
+        for d, ax in enumerate("xyz"):
+            p.retain_xyz[d] = prec.get("Retain Nodes (%s)" % ax, -1)
+        for l in range(8):
+            p.retain_at_level[l] = prec.get("Retain Nodes at Level %d" % l, -1)
         p.retain_pressures = prob.get("Retained Pressure Nodes", -1)
         p.link_velocities = int(prec.get("Eliminate Velocities Together", True))
         p.link_retained = int(prec.get("Eliminate Retained Nodes Together", True))

@@ -57,6 +57,8 @@ void hymls_mi_default_params(hymls_mi_params* p) {
   p->sx = 4; p->sy = p->sz = -1; p->cx = p->cy = p->cz = -1;
   p->levels = 1; p->partitioner = 0; p->retain_nodes = -1; p->retain_pressures = -1;
   p->link_velocities = 1; p->link_retained = 1; p->fix_pressure_level = 1; p->nfix = 0;
+  for (int d = 0; d < 3; d++) p->retain_xyz[d] = -1;
+  for (int l = 0; l < 8; l++) p->retain_at_level[l] = -1;
 }
 
 static Params convert(const hymls_mi_params* q) {
@@ -70,7 +72,11 @@ static Params convert(const hymls_mi_params* q) {
   HYMLS_CHECK(p.sx > 1, -2, "Separator Length not set correctly");
   p.cx = q->cx < 0 ? p.sx : q->cx; p.cy = q->cy < 0 ? p.cx : q->cy; p.cz = p.nz > 1 ? (q->cz < 0 ? p.cx : q->cz) : 1;
   HYMLS_CHECK(p.cx > 1, -2, "Coarsening Factor not set correctly");
-  p.rx = p.ry = p.rz = q->retain_nodes;
+  p.retain = q->retain_nodes;
+  for (int d = 0; d < 3; d++) p.retain_xyz[d] = q->retain_xyz[d];
+  for (int l = 0; l < 8; l++) p.retain_at_level[l] = q->retain_at_level[l];
+  p.level = 0;
+  p.set_retain();
   p.levels = q->levels;
   p.partitioner = q->partitioner;
   p.link_velocities = q->link_velocities != 0; p.link_retained = q->link_retained != 0;

@@ -51,6 +51,9 @@ typedef struct hymls_mi_params {
   int32_t nfix;                 /* explicit "Fix GID n" entries (0: derive) */
   int32_t fix_gid[4];
   int32_t variable_type[8];     /* per dof: 0 Laplace/Velocity_V,1 U,2 V,3 W,4 Pressure,5 Interior; used if dof given and equations<0 */
+  int32_t retain_xyz[3];        /* "Retain Nodes (x|y|z)" (-1: unset) */
+  int32_t retain_at_level[8];   /* "Retain Nodes at Level k", k = 0.. (-1: unset); precedence as the reference,
+                                   src/HYMLS_BasePartitioner.cpp:108-137: (x|y|z), then at-level, then "Retain Nodes" */
 } hymls_mi_params;
 
 /* fill *p with the reference defaults (everything -1 / default flags). */

@@ -72,6 +72,8 @@ class Preconditioner : public Ifpack_Preconditioner {
     p_.levels = prec.get("Number of Levels", 1);
     p_.partitioner = prec.get("Partitioner", std::string("Cartesian")) == "Skew Cartesian" ? 1 : 0;
     p_.retain_nodes = prec.get("Retain Nodes", -1);
+    p_.retain_xyz[0] = prec.get("Retain Nodes (x)", -1); p_.retain_xyz[1] = prec.get("Retain Nodes (y)", -1); p_.retain_xyz[2] = prec.get("Retain Nodes (z)", -1);
+    for (int l = 0; l < 8; l++) p_.retain_at_level[l] = prec.get("Retain Nodes at Level " + std::to_string(l), -1);
     p_.retain_pressures = prec.get("Retained Pressure Nodes", -1);
     p_.link_velocities = prec.get("Eliminate Velocities Together", true) ? 1 : 0;
     p_.link_retained = prec.get("Eliminate Retained Nodes Together", true) ? 1 : 0;

@@ -26,9 +26,13 @@ class Params:
     cx: int = -1
     cy: int = -1
     cz: int = -1
-    rx: int = -1  # "Retain Nodes"
+    rx: int = -1  # "Retain Nodes" (finalize / next_level resolve them per level, BasePartitioner.cpp:108-137)
     ry: int = -1
     rz: int = -1
+    retain_xyz: tuple = (-1, -1, -1)          # "Retain Nodes (x|y|z)"
+    retain_at_level: dict = field(default_factory=dict)   # "Retain Nodes at Level k"
+    level: int = 0
+    retain: int = None
     levels: int = 1  # XML "Number of Levels" (0-based, SURVEY top)
     variable_types: list = field(default_factory=list)
     retain_pressures: int = 1
@@ -53,10 +57,9 @@ class Params:
             p.cy = p.cx
         if p.cz == -1:
             p.cz = p.cx if p.nz > 1 else 1
-        if p.ry == -1:
-            p.ry = p.rx
-        if p.rz == -1:
-            p.rz = p.rx
+        if p.retain is None:
+            p.retain = p.rx            # "Retain Nodes"
+        p._set_retain()
         if not p.variable_types:
             if p.equations == "Laplace":
                 p.dof = 1
@@ -70,9 +73,17 @@ class Params:
                 raise ValueError("'Equations' parameter not recognized")
         return p
 
+    def _set_retain(self):
+        at = self.retain_at_level.get(self.level, -1)
+        r = [self.retain_xyz[d] if self.retain_xyz[d] != -1 else (at if at != -1 else self.retain) for d in range(3)]
+        self.rx, self.ry, self.rz = r
+
     def next_level(self):
-        """SetNextLevelParameters (BasePartitioner.cpp:321-346)."""
-        return replace(self, sx=self.sx * self.cx, sy=self.sy * self.cy, sz=self.sz * self.cz)
+        """SetNextLevelParameters (BasePartitioner.cpp:321-346); the partitioner of the next level reads its own
+        "Retain Nodes at Level k" (:112)."""
+        q = replace(self, sx=self.sx * self.cx, sy=self.sy * self.cy, sz=self.sz * self.cz, level=self.level + 1)
+        q._set_retain()
+        return q
 
 
 def _start_end(pos, idx, idx_max, dim, mx, perio=False):

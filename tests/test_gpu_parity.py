@@ -426,6 +426,13 @@ def test_compute_is_bitwise_reproducible(gpu_lib, eq, n, sx, levels, cx, part):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_retain_nodes_gpu(gpu_lib, which):
+    from test_hostsim_parity import RETAIN, retain_nodes_case
+    retain_nodes_case(gpu_lib, *RETAIN[which])
+
+
+@pytest.mark.gpu
 def test_two_live_handles_alternate(gpu_lib):
     """every handle owns its device context (stream, arenas, profiling marks): two preconditioners alive at the same
     time, applied alternately, give exactly what each gives alone (reference: any number of Preconditioner objects)."""

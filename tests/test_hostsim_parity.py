@@ -2,6 +2,8 @@
 end-to-end through the C ABI with the TEST-ONLY device simulator (tests/hostsim), compared with
 the oracle.  This validates the integer plans the GPU kernels execute; the kernels themselves
 are covered by the -m gpu tests."""
+import os
+
 import numpy as np
 import pytest
 
@@ -238,3 +240,54 @@ def test_multivector_apply_inverse(hostsim_lib, eq, n, sx, levels, cx, part):
         for j in range(nvec):
             assert np.array_equal(X[:, j], P.ApplyInverse(B[:, j].copy()))
         assert rel_diff(X[:, nvec - 1], O.apply_inverse(B[:, nvec - 1])) < 1e-8
+
+
+RETAIN = [
+    ({"Retain Nodes": 2}, dict(rx=2)),
+    ({"Retain Nodes (x)": 2, "Retain Nodes (z)": 3}, dict(retain_xyz=(2, -1, 3))),
+    ({"Retain Nodes at Level 1": 2}, dict(retain_at_level={1: 2})),
+    ({"Retain Nodes": 2, "Retain Nodes at Level 0": 1}, dict(rx=2, retain_at_level={0: 1})),
+]
+
+
+def retain_nodes_case(lib, extra, kw):
+    """"Retain Nodes" > 1 (several V-sums per separator, Cartesian partitioner: reference
+    src/HYMLS_CartesianPartitioner.cpp:289-296) with the reference's parameter precedence "(x|y|z)" > "at Level k" >
+    "Retain Nodes" (src/HYMLS_BasePartitioner.cpp:108-137): level sizes and ApplyInverse equal the oracle's; more retained
+    nodes never need more CG iterations."""
+    from oracle import krylov
+    A, tv = problem("Laplace", 16)
+    P = product_prec(A, tv, xml_params("Laplace", 16, 4, 2, cx=2, extra=extra), lib)
+    O = oracle_prec(A, tv, "Laplace", 16, 4, 2, cx=2, **kw)
+    assert [s[1] for s in P.level_sizes()] == [s[1] for s in O.level_sizes()]
+    b = np.random.default_rng(1).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-10
+    P1 = product_prec(A, tv, xml_params("Laplace", 16, 4, 2, cx=2), lib)
+    assert P.level_sizes()[1][1] >= P1.level_sizes()[1][1]
+    rhs = A @ np.random.default_rng(2).uniform(-1, 1, A.shape[0])
+    its = krylov.pcg(lambda v: A @ v, rhs, P.ApplyInverse, tol=1e-8, maxit=200)[1]
+    its1 = krylov.pcg(lambda v: A @ v, rhs, P1.ApplyInverse, tol=1e-8, maxit=200)[1]
+    assert its <= its1
+
+
+@pytest.mark.parametrize("extra,kw", RETAIN)
+def test_retain_nodes(hostsim_lib, extra, kw):
+    retain_nodes_case(hostsim_lib, extra, kw)
+
+
+def test_retain_nodes_stokes_2d(hostsim_lib):
+    """2D Stokes-C, Cartesian partitioner, two retained nodes per separator: oracle parity of the two-level method"""
+    from oracle import galeri
+    from oracle.hymls import Preconditioner as OraclePrec
+    import scipy.sparse as sp
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "drivencavity32_2d_re0.npz"))
+    n = 32
+    A = sp.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=(3 * n * n, 3 * n * n))
+    tv = galeri.create_testvector(A)
+    prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 2, "nx": n, "ny": n, "nz": 1},
+           "Preconditioner": {"Separator Length": 8, "Number of Levels": 1, "Partitioner": "Cartesian", "Retain Nodes": 2}}
+    P = product_prec(A, tv, prm, hostsim_lib)
+    O = OraclePrec(A, Params(nx=n, ny=n, nz=1, sx=8, levels=1, equations="Stokes-C", dim=2, rx=2).finalize(), testvector=tv).compute()
+    assert [s[1] for s in P.level_sizes()] == [s[1] for s in O.level_sizes()]
+    b = np.random.default_rng(3).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-9

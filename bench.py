@@ -174,6 +174,22 @@ def main():
                "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
         comm = RcclComm(local_rank, lib=lib) if native else TorchComm(dev)
         P = hymls_amd.Preconditioner(None, prm, device=local_rank, lib=lib, comm=comm, rank_grid=(px, py, pz))
+        if native:
+            # the built-in transport checks itself on every rank before any work is sharded over it; if a rank fails, all
+            # ranks switch to the callback transport (still the sharded problem, and config.parallelism says which one ran)
+            bad = torch.tensor([1.0 if P.CommSelfTest() != 0 else 0.0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if bad.item() > 0:
+                sys.stderr.write("bench.py: built-in RCCL transport failed its self-test on some rank: torch.distributed transport\n")
+                native = False
+                err = transport_selftest(dev, backend)
+                if err:
+                    sys.stderr.write("bench.py: sharded transport self-test failed on rank %d (%s); no fallback\n" % (rank, err))
+                    dist.destroy_process_group()
+                    sys.exit(3)
+                comm = TorchComm(dev)
+                P = hymls_amd.Preconditioner(None, prm, device=local_rank, lib=lib, comm=comm, rank_grid=(px, py, pz))
         t0 = time.time()
         req = P.RequiredRows()
         rows = hymls_amd.generate_problem(PROBLEM[args.problem], nx, ny, nz, re=args.re, gids=req, lib=lib)

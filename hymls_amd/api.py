@@ -71,6 +71,7 @@ def load_library(path=None):
         "hymls_mi_rccl_comm_init": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
         "hymls_mi_rccl_comm_destroy": (None, [C.c_void_p]),
         "hymls_mi_set_comm_rccl": (C.c_int, [H, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+        "hymls_mi_comm_selftest": (C.c_int, [H]),
         "hymls_mi_required_rows": (C.c_int, [H, _I64P, _I32P]),
         "hymls_mi_set_matrix_rows": (C.c_int, [H, C.c_int64, _I32P, _I32P, _I32P, _F64P]),
         "hymls_mi_owned_rows": (C.c_int, [H, _I64P, _I32P]),
@@ -253,6 +254,10 @@ class Preconditioner:
             self.SetTestVector(testVector)
 
     # --- sharded runs
+    def CommSelfTest(self):
+        """collective: 0 if the transport of this sharded handle moved a stamped all-to-all correctly, else the error code"""
+        return self._lib.hymls_mi_comm_selftest(self._h)
+
     def RequiredRows(self):
         n = C.c_int64()
         self._check(self._lib.hymls_mi_required_rows(self._h, C.byref(n), None))

@@ -171,6 +171,30 @@ int hymls_mi_set_comm_rccl(hymls_mi_t* h, void* nccl_comm, int px, int py, int p
   API_END(h)
 }
 
+int hymls_mi_comm_selftest(hymls_mi_t* h) {
+  if (!h) return -2;
+  API_BEGIN
+  const Comm& c = h->comm;
+  HYMLS_CHECK(c.alltoallv && c.alloc, -2, "no transport set (hymls_mi_set_comm / hymls_mi_set_comm_rccl)");
+  // uneven device all-to-all of stamped doubles: rank r sends (r + q) % 3 + 1 values r * 1000 + q + 0.25 k to rank q
+  std::vector<int64_t> sc(c.size), rc(c.size);
+  int64_t ns = 0, nr = 0;
+  for (int q = 0; q < c.size; q++) { sc[q] = (c.rank + q) % 3 + 1; rc[q] = (q + c.rank) % 3 + 1; ns += sc[q]; nr += rc[q]; }
+  dvec hs((size_t)ns), hr((size_t)nr, -1.0);
+  { int64_t o = 0; for (int q = 0; q < c.size; q++) for (int64_t k = 0; k < sc[q]; k++) hs[o++] = c.rank * 1000.0 + q + 0.25 * k; }
+  double* sb = c.send_arena(ns);
+  double* rb = c.recv_arena(nr);
+  dev::h2d(sb, hs.data(), (size_t)ns * sizeof(double));
+  const int ierr = c.alltoallv(c.ctx, sb, sc.data(), rb, rc.data(), (int32_t)sizeof(double), 1);
+  HYMLS_CHECK(ierr == 0, -3, std::string("transport self-test: device all-to-all failed ") + rccl_last_error(c));
+  dev::d2h(hr.data(), rb, (size_t)nr * sizeof(double));
+  { int64_t o = 0; for (int q = 0; q < c.size; q++) for (int64_t k = 0; k < rc[q]; k++) HYMLS_CHECK(hr[o++] == q * 1000.0 + c.rank + 0.25 * k, -3, "transport self-test: wrong data"); }
+  // host-side exchange (setup path): counts round trip
+  std::vector<int64_t> back = c.exchange_counts(sc);
+  for (int q = 0; q < c.size; q++) HYMLS_CHECK(back[q] == rc[q], -3, "transport self-test: wrong host data");
+  API_END(h)
+}
+
 int hymls_mi_required_rows(hymls_mi_t* h, int64_t* n, int32_t* gids) {
   if (!h || !n) return -2;
   API_BEGIN

@@ -105,6 +105,9 @@ int hymls_mi_rccl_unique_id(char* id128);
 int hymls_mi_rccl_comm_init(const char* id128, int rank, int size, int device, void** nccl_comm);
 void hymls_mi_rccl_comm_destroy(void* nccl_comm);
 int hymls_mi_set_comm_rccl(hymls_mi_t* h, void* nccl_comm /* ncclComm_t */, int px, int py, int pz);
+/* collective check of the transport of a sharded handle (either kind): an uneven device all-to-all of stamped values on the
+ * handle's stream and a host-side count exchange; 0 if this rank sent and received what it should. */
+int hymls_mi_comm_selftest(hymls_mi_t* h);
 /* the rows this rank has to be given: interiors and separators of its subdomains (the overlapping
  * row map of the reference).  Two-call protocol (gids == NULL: count only); ascending gids. */
 int hymls_mi_required_rows(hymls_mi_t* h, int64_t* n, int32_t* gids);

@@ -58,6 +58,7 @@ def main():
         comm = TorchComm(device)
     P = hymls_amd.Preconditioner(None, prm, lib=lib, comm=comm, rank_grid=rank_grid(world),
                                  device=int(os.environ.get("LOCAL_RANK", "0")) if mode in ("gpu-nccl", "gpu-rccl") else 0)
+    assert P.CommSelfTest() == 0, "transport self-test failed"
     req = P.RequiredRows()
     rows = hymls_amd.generate_rows(eq, nx, ny, nz, req, a=a, lib=lib)
     P.SetMatrixRows(req, rows)

@@ -238,6 +238,13 @@ void sblock_transform(int32_t nS, int32_t ng, const int32_t* gptr, const double*
 // out[b][k] = sblock[b][pick[k]]  (extraction of the kept entries)
 void sblock_extract(int32_t nS, int64_t npick, const int32_t* pick, const double* sblock,
                     double* out, int64_t out_stride, int32_t nbc);
+// transform + extraction in one read pass (device_hip.hip: k_sblock_kept): the record of every slot = V-sum x V-sum
+// entries (ngl x ngl, column-major) followed by the non-V-sum block of every linked set
+struct KeptD {
+  int32_t nS, ngl;
+  const int32_t* gptr; const int32_t* glink; const int32_t* goff; const int64_t* lboff; const int32_t* lblen;
+};
+void sblock_kept(const KeptD& K, const double* tv, const double* sblock, double* out, int64_t out_stride, int32_t nbc);
 // batched dense inverse with partial pivoting: nblk blocks of order nb (col-major), in place
 void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag);
 // y[ids] = Binv x[ids] for nblk blocks of order nb; ids: [nblk][nb]

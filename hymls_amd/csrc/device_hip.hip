@@ -2505,6 +2505,107 @@ void sblock_extract(int32_t nS, int64_t npick, const int32_t* pick, const double
   }
 }
 
+// ---- kept entries of the transformed separator block in ONE read pass (AssembleTransformAndDrop / ConstructSCPart of the
+// reference, src/HYMLS_SchurPreconditioner.cpp:698-986: two-sided Householder per group on the dense matrix, then only the
+// V-sum x V-sum entries and the non-V-sum block of every linked set are kept).  With H_g = gam_g u_g u_g' + bet_g I
+// (bet = -1, gam = 1 / (nrm v1) for an active transform; bet = +1, gam = 0 for the identity, reference
+// src/HYMLS_Householder.cpp:38-80) the kept entries of the block of row group I and column group J are
+//   T[a,b] = gam_I gam_J u_I[a] t u_J[b] + gam_I bet_J u_I[a] r_b + bet_I gam_J q_a u_J[b] + bet_I bet_J S[a,b]
+//   q = S[I,J] u_J,   r = u_I' S[I,J],   t = u_I' S[I,J] u_J,
+// so the transformed matrix never has to be written: a workgroup owns one (slot, column group J), streams the columns
+// of J once with the rows on consecutive lanes (q for every row at once), and finishes with segmented sums over the row
+// groups.  The separate transform + extract passes read and wrote the nS^2 block four times.
+__global__ void __launch_bounds__(256) k_sblock_kept(KeptD K, const double* __restrict__ tv, const double* __restrict__ sblock,
+                                                     double* __restrict__ out, int64_t out_stride) {
+  extern __shared__ double sh[];           // u[nS] | q[nS] | c0[nS] | gam[ngl] | bet[ngl] | tI[ngl] | r0[ngl]
+  const int nS = K.nS, ngl = K.ngl, tid = threadIdx.x;
+  const int slot = blockIdx.y, J = blockIdx.x;
+  double* u = sh; double* q = u + nS; double* c0 = q + nS;
+  double* gam = c0 + nS; double* bet = gam + ngl; double* tI = bet + ngl; double* r0 = tI + ngl;
+  const double* S = sblock + (int64_t)slot * nS * nS;
+  const double* v = tv + (int64_t)slot * nS;
+  double* rec = out + (int64_t)slot * out_stride;
+  // Householder data of every group of this slot
+  for (int g = tid; g < ngl; g += 256) {
+    const int pos = K.gptr[g], n = K.gptr[g + 1] - pos;
+    double sg, nrm, v1, fac1;
+    const bool act = n > 0 && hh_setup(v + pos, n, sg, nrm, v1, fac1);
+    gam[g] = act ? fac1 : 0.0;
+    bet[g] = act ? -1.0 : 1.0;
+    for (int i = 0; i < n; i++) u[pos + i] = act ? (i == 0 ? v1 : sg * v[pos + i]) : 0.0;
+  }
+  __syncthreads();
+  const int jb = K.gptr[J], nJ = K.gptr[J + 1] - jb;
+  // q_i = sum_j S[i, j] u_J[j] for every row i, c0_i = S[i, first column of J]
+  for (int i = tid; i < nS; i += 256) {
+    const double* __restrict__ p = S + i + (int64_t)nS * jb;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const double first = p[0];
+    int j = 0;
+    for (; j + 3 < nJ; j += 4) {
+      const double s0 = p[(int64_t)nS * j], s1 = p[(int64_t)nS * (j + 1)], s2 = p[(int64_t)nS * (j + 2)], s3 = p[(int64_t)nS * (j + 3)];
+      a0 += s0 * u[jb + j]; a1 += s1 * u[jb + j + 1]; a2 += s2 * u[jb + j + 2]; a3 += s3 * u[jb + j + 3];
+    }
+    for (; j < nJ; j++) a0 += p[(int64_t)nS * j] * u[jb + j];
+    q[i] = (a0 + a1) + (a2 + a3);
+    c0[i] = first;
+  }
+  __syncthreads();
+  // segmented sums over the row groups: t_I = u_I' q_I, r0_I = u_I' c0_I
+  for (int I = tid; I < ngl; I += 256) {
+    const int ib = K.gptr[I], nI = K.gptr[I + 1] - ib;
+    double t = 0.0, r = 0.0;
+    for (int i = 0; i < nI; i++) { t += u[ib + i] * q[ib + i]; r += u[ib + i] * c0[ib + i]; }
+    tI[I] = t; r0[I] = r;
+  }
+  __syncthreads();
+  const double gJ = gam[J], bJ = bet[J], uJ0 = nJ > 0 ? u[jb] : 0.0;
+  // V-sum x V-sum entries of column J
+  for (int I = tid; I < ngl; I += 256) {
+    const int ib = K.gptr[I];
+    const double gI = gam[I], bI = bet[I], uI0 = u[ib];
+    rec[I + (int64_t)ngl * J] = gI * gJ * uI0 * tI[I] * uJ0 + gI * bJ * uI0 * r0[I] + bI * gJ * q[ib] * uJ0 + bI * bJ * c0[ib];
+  }
+  // the non-V-sum block of the linked set of J: row groups I of the same set
+  const int L = K.glink[J];
+  if (L < 0 || nJ < 2) return;
+  const int64_t boff = K.lboff[L];
+  const int blen = K.lblen[L];
+  for (int I = 0; I < ngl; I++) {
+    if (K.glink[I] != L) continue;
+    const int ib = K.gptr[I], nI = K.gptr[I + 1] - ib;
+    if (nI < 2) continue;
+    const double gI = gam[I], bI = bet[I];
+    __syncthreads();                       // (q of the previous partner group is done with c0 as scratch)
+    // r_b = u_I' S[I, b] for the columns b of J (scratch: c0[0 .. nJ))
+    for (int b = tid; b < nJ; b += 256) {
+      const double* __restrict__ p = S + ib + (int64_t)nS * (jb + b);
+      double r = 0.0;
+      for (int i = 0; i < nI; i++) r += u[ib + i] * p[i];
+      c0[b] = r;
+    }
+    __syncthreads();
+    const double t = tI[I];
+    for (int e = tid; e < (nI - 1) * (nJ - 1); e += 256) {
+      const int a = 1 + e % (nI - 1), b = 1 + e / (nI - 1);
+      const double sab = S[(ib + a) + (int64_t)nS * (jb + b)];
+      const double val = gI * gJ * u[ib + a] * t * u[jb + b] + gI * bJ * u[ib + a] * c0[b] + bI * gJ * q[ib + a] * u[jb + b] + bI * bJ * sab;
+      rec[boff + (K.goff[I] + a - 1) + (int64_t)blen * (K.goff[J] + b - 1)] = val;
+    }
+  }
+}
+void sblock_kept(const KeptD& K, const double* tv, const double* sblock, double* out, int64_t out_stride, int32_t nbc) {
+  if (K.nS <= 0 || K.ngl <= 0 || nbc <= 0) return;
+  const size_t shm = (size_t)(3 * K.nS + 4 * K.ngl) * sizeof(double);
+  if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_sblock_kept, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  for (int s0 = 0; s0 < nbc; s0 += 65535) {
+    const int ns = std::min(65535, nbc - s0);
+    hipLaunchKernelGGL(k_sblock_kept, dim3(K.ngl, ns), dim3(256), shm, g_stream, K, tv + (int64_t)s0 * K.nS,
+                       sblock + (int64_t)s0 * K.nS * K.nS, out + (int64_t)s0 * out_stride, out_stride);
+    launch_check();
+  }
+}
+
 // in-place Gauss-Jordan inversion with partial pivoting, one workgroup per block
 // one workgroup per block; `all` != nullptr: blocks of any order from a descriptor table (one launch for a
 // whole level, so that the few large blocks of the coarser levels run side by side), else nblk blocks of order nb0

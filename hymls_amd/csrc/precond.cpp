@@ -530,9 +530,11 @@ struct LevelSolver::Cls {
   int32_t ngl = 0;
   int32_t* d_pick = nullptr;
   int32_t* d_lgptr = nullptr;
+  int32_t *d_glink = nullptr, *d_goff = nullptr, *d_lblen = nullptr;   // linked-set tables of the kept-entries kernel
+  int64_t* d_lboff = nullptr;
   dvec tvloc;
   double* d_tvloc = nullptr;
-  ~Cls() { dev::free(d_pick); dev::free(d_lgptr); dev::free(d_tvloc); }
+  ~Cls() { dev::free(d_pick); dev::free(d_lgptr); dev::free(d_tvloc); dev::free(d_glink); dev::free(d_goff); dev::free(d_lblen); dev::free(d_lboff); }
 };
 
 void make_local_csr(int64_t nrows, const int32_t* row_gids, const int32_t* rowptr, const int32_t* col_gids,
@@ -1334,6 +1336,18 @@ void LevelSolver::build_schur_setup() {
     C.d_pick = dev::upload(C.pick);
     C.d_lgptr = dev::upload(C.lgptr);
     C.d_tvloc = dev::upload(C.tvloc);
+    if (!direct_schur_) {
+      ivec glink(C.ngl, -1), goff(C.ngl, 0), lblen(C.blk_len.begin(), C.blk_len.end());
+      std::vector<int64_t> lboff(C.blk_off.begin(), C.blk_off.end());
+      for (size_t li = 0; li < C.llinked.size(); li++) {
+        int32_t off = 0;
+        for (int gi : C.llinked[li]) {
+          if (C.blk_len[li] > 0) { glink[gi] = (int32_t)li; goff[gi] = off; }
+          off += C.lgptr[gi + 1] - C.lgptr[gi] - 1;
+        }
+      }
+      C.d_glink = dev::upload(glink); C.d_goff = dev::upload(goff); C.d_lblen = dev::upload(lblen); C.d_lboff = dev::upload(lboff);
+    }
   }
   lap("pull lists");
   // ---- tables of the fused interior solve (classes whose vectors fit in LDS)
@@ -1525,10 +1539,15 @@ void LevelSolver::compute() {
       C.lu.factor_chunk(d_kval_, b0, nbc);
       C.lu.repack_chunk(b0, nbc);
       if (C.pat.nS == 0) continue;
-      if (!direct_schur_)
-        dev::sblock_transform(C.pat.nS, C.ngl, C.d_lgptr, C.d_tvloc + (size_t)b0 * C.pat.nS, C.lu.batch.sblock, nbc);
-      dev::sblock_extract(C.pat.nS, C.ext_size, C.d_pick, C.lu.batch.sblock,
-                          d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size, C.ext_size, nbc);
+      if (!direct_schur_) {
+        // orthogonal transformation + dropping: only the kept entries are formed, in one read pass over the block
+        const dev::KeptD K{C.pat.nS, C.ngl, C.d_lgptr, C.d_glink, C.d_goff, C.d_lboff, C.d_lblen};
+        dev::sblock_kept(K, C.d_tvloc + (size_t)b0 * C.pat.nS, C.lu.batch.sblock, d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size,
+                         C.ext_size, nbc);
+      } else {
+        dev::sblock_extract(C.pat.nS, C.ext_size, C.d_pick, C.lu.batch.sblock,
+                            d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size, C.ext_size, nbc);
+      }
     }
   }
   if (side) dev::join_streams();

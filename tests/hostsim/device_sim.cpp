@@ -403,6 +403,27 @@ void sblock_transform(int32_t nS, int32_t ng, const int32_t* gptr, const double*
   }
 }
 
+// kept entries of the transformed block: the simulator transforms a copy and reads the kept positions
+void sblock_kept(const KeptD& K, const double* tv, const double* sblock, double* out, int64_t out_stride, int32_t nbc) {
+  const int nS = K.nS, ngl = K.ngl;
+  std::vector<double> T((size_t)nS * nS);
+  for (int s = 0; s < nbc; s++) {
+    std::memcpy(T.data(), sblock + (int64_t)s * nS * nS, (size_t)nS * nS * sizeof(double));
+    sblock_transform(nS, ngl, K.gptr, tv + (int64_t)s * nS, T.data(), 1);
+    double* rec = out + (int64_t)s * out_stride;
+    for (int J = 0; J < ngl; J++)
+      for (int I = 0; I < ngl; I++) {
+        rec[I + (int64_t)ngl * J] = T[K.gptr[I] + (int64_t)nS * K.gptr[J]];
+        if (K.glink[I] >= 0 && K.glink[I] == K.glink[J]) {
+          const int L = K.glink[I], nI = K.gptr[I + 1] - K.gptr[I], nJ = K.gptr[J + 1] - K.gptr[J];
+          for (int b = 1; b < nJ; b++)
+            for (int a = 1; a < nI; a++)
+              rec[K.lboff[L] + (K.goff[I] + a - 1) + (int64_t)K.lblen[L] * (K.goff[J] + b - 1)] = T[(K.gptr[I] + a) + (int64_t)nS * (K.gptr[J] + b)];
+        }
+      }
+  }
+}
+
 void sblock_extract(int32_t nS, int64_t npick, const int32_t* pick, const double* sblock, double* out,
                     int64_t out_stride, int32_t nbc) {
   for (int b = 0; b < nbc; b++)

@@ -386,6 +386,80 @@ __device__ inline void block_absmax(const double* S, int64_t ld, int w, bool low
   atomicMax(acc, (unsigned long long)__double_as_longlong(m));
 }
 
+// LU without pivoting of the w x w block S (LDS, column-major, leading dimension w) followed by the in-place inverses of
+// both factors: strictly lower part <- L^{-1} (unit diagonal implied), upper part incl. diagonal <- U^{-1}.  Executed by
+// the whole workgroup with ONE barrier per elimination / inversion step (the multipliers are scaled after the loop; the
+// column an inversion step needs is copied into the other half of xv during the step before).  xv: 2 w doubles.
+// Element growth is measured on the way (see block_absmax); s_bad |= 1 for a zero / non-finite pivot, |= 2 for growth.
+__device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_bad, unsigned long long* s_m0,
+                                           unsigned long long* s_ml, unsigned long long* s_mu) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  block_absmax(S, w, w, true, true, s_m0);
+  for (int k = 0; k < w; k++) {
+    const double piv = S[k + w * k];
+    if (tid == 0 && (piv == 0.0 || !isfinite(piv))) *s_bad |= 1;
+    const double ip = 1.0 / piv;
+    const int rem = w - k - 1;
+    for (int t = tid; t < rem * rem; t += nt) {
+      const int i = k + 1 + t % rem, j = k + 1 + t / rem;
+      S[i + w * j] -= (S[i + w * k] * ip) * S[k + w * j];
+    }
+    __syncthreads();
+  }
+  for (int t = tid; t < w * w; t += nt) {
+    const int i = t % w, j = t / w;
+    if (i > j) S[t] *= 1.0 / S[j + w * j];
+  }
+  __syncthreads();
+  block_absmax(S, w, w, true, false, s_ml);
+  block_absmax(S, w, w, false, true, s_mu);
+  __syncthreads();
+  if (tid == 0 && (__longlong_as_double((long long)*s_ml) > GROWTH_LIMIT ||
+                   __longlong_as_double((long long)*s_mu) > GROWTH_LIMIT * __longlong_as_double((long long)*s_m0))) *s_bad |= 2;
+  // inverse of the unit lower factor, columns from the last to the first:
+  // X[j+1:, j] = - X[j+1:, j+1:] * L[j+1:, j]   (X[j+1:, j+1:] already holds the inverse)
+  double* xa = xv;
+  double* xb = xv + w;
+  if (w >= 2) for (int i = w - 1 + tid; i < w; i += nt) xa[i] = S[i + w * (w - 2)];
+  __syncthreads();
+  for (int j = w - 2; j >= 0; j--) {
+    for (int i = j + 1 + tid; i < w; i += nt) {
+      double s0 = xa[i] /* unit diagonal of X */, s1 = 0.0, s2 = 0.0, s3 = 0.0;    // four chains instead of one of length i - j
+      int k = j + 1;
+      for (; k + 3 < i; k += 4) {
+        s0 += S[i + w * k] * xa[k]; s1 += S[i + w * (k + 1)] * xa[k + 1];
+        s2 += S[i + w * (k + 2)] * xa[k + 2]; s3 += S[i + w * (k + 3)] * xa[k + 3];
+      }
+      for (; k < i; k++) s0 += S[i + w * k] * xa[k];
+      S[i + w * j] = -((s0 + s1) + (s2 + s3));
+    }
+    if (j > 0) for (int i = j + tid; i < w; i += nt) xb[i] = S[i + w * (j - 1)];   // the column of the next step
+    __syncthreads();
+    double* t = xa; xa = xb; xb = t;
+  }
+  // inverse of the upper factor, columns from the first to the last:
+  // Y[j,j] = 1/U[j,j]; Y[0:j, j] = -Y[0:j, 0:j] * U[0:j, j] * Y[j,j]
+  for (int i = tid; i < 1 && i < w; i += nt) xa[i] = S[i];
+  __syncthreads();
+  for (int j = 0; j < w; j++) {
+    const double d = 1.0 / xa[j];
+    for (int i = tid; i < j; i += nt) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = i;
+      for (; k + 3 < j; k += 4) {
+        s0 += S[i + w * k] * xa[k]; s1 += S[i + w * (k + 1)] * xa[k + 1];
+        s2 += S[i + w * (k + 2)] * xa[k + 2]; s3 += S[i + w * (k + 3)] * xa[k + 3];
+      }
+      for (; k < j; k++) s0 += S[i + w * k] * xa[k];
+      S[i + w * j] = -((s0 + s1) + (s2 + s3)) * d;
+    }
+    if (tid == 0) S[j + w * j] = d;
+    if (j + 1 < w) for (int i = tid; i <= j + 1; i += nt) xb[i] = S[i + w * (j + 1)];
+    __syncthreads();
+    double* t = xa; xa = xb; xb = t;
+  }
+}
+
 // LD: doubles of LDS (pivot block + work vector, then staging of the panel products, then the GEMM slabs: the three
 // uses follow each other).  3072 (24 KiB, 6 workgroups per CU) for pivot blocks up to 54 wide, else 6144 (up to 77).
 template <bool PROF, int LD>
@@ -432,64 +506,13 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
   double* Lp = fac + F.lp_off;
   double* Q = fac + F.q_off;
   const int64_t ld = w + ri;
-  if (w * w + w <= LD) {
+  if (w * w + 2 * w <= LD) {
     // 2+3 (LDS path): LU of the pivot block and in-place triangular inverses inside LDS
     double* S = lds;
     double* xv = lds + w * w;
     for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + (int64_t)m * (t / w)];
     __syncthreads();
-    block_absmax(S, w, w, true, true, &s_m0);
-    for (int k = 0; k < w; k++) {
-      const double piv = S[k + w * k];
-      if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
-      const double ip = 1.0 / piv;
-      __syncthreads();
-      for (int i = k + 1 + tid; i < w; i += FT) S[i + w * k] *= ip;
-      __syncthreads();
-      const int rem = w - k - 1;
-      for (int t = tid; t < rem * rem; t += FT) {
-        const int i = k + 1 + t % rem, j = k + 1 + t / rem;
-        S[i + w * j] -= S[i + w * k] * S[k + w * j];
-      }
-      __syncthreads();
-    }
-    block_absmax(S, w, w, true, false, &s_ml);
-    block_absmax(S, w, w, false, true, &s_mu);
-    __syncthreads();
-    if (tid == 0 && (__longlong_as_double((long long)s_ml) > GROWTH_LIMIT ||
-                     __longlong_as_double((long long)s_mu) > GROWTH_LIMIT * __longlong_as_double((long long)s_m0))) s_bad |= 2;
-    for (int j = w - 2; j >= 0; j--) {
-      for (int i = j + 1 + tid; i < w; i += FT) xv[i] = S[i + w * j];
-      __syncthreads();
-      for (int i = j + 1 + tid; i < w; i += FT) {
-        double s0 = xv[i], s1 = 0.0, s2 = 0.0, s3 = 0.0;    // four chains instead of one dependent chain of length i - j
-        int k = j + 1;
-        for (; k + 3 < i; k += 4) {
-          s0 += S[i + w * k] * xv[k]; s1 += S[i + w * (k + 1)] * xv[k + 1];
-          s2 += S[i + w * (k + 2)] * xv[k + 2]; s3 += S[i + w * (k + 3)] * xv[k + 3];
-        }
-        for (; k < i; k++) s0 += S[i + w * k] * xv[k];
-        S[i + w * j] = -((s0 + s1) + (s2 + s3));
-      }
-      __syncthreads();
-    }
-    for (int j = 0; j < w; j++) {
-      for (int i = tid; i < j; i += FT) xv[i] = S[i + w * j];
-      const double d = 1.0 / S[j + w * j];
-      __syncthreads();
-      for (int i = tid; i < j; i += FT) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int k = i;
-        for (; k + 3 < j; k += 4) {
-          s0 += S[i + w * k] * xv[k]; s1 += S[i + w * (k + 1)] * xv[k + 1];
-          s2 += S[i + w * (k + 2)] * xv[k + 2]; s3 += S[i + w * (k + 3)] * xv[k + 3];
-        }
-        for (; k < j; k++) s0 += S[i + w * k] * xv[k];
-        S[i + w * j] = -((s0 + s1) + (s2 + s3)) * d;
-      }
-      if (tid == 0) S[j + w * j] = d;
-      __syncthreads();
-    }
+    lds_lu_and_inverses(S, w, xv, &s_bad, &s_m0, &s_ml, &s_mu);
     for (int t = tid; t < w * w; t += FT) Lp[(t % w) + ld * (t / w)] = S[t];
   } else {
     // 2. LU (no pivoting) of the w x w pivot block in global memory (wide pivot blocks)
@@ -615,7 +638,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
 void factor_level(const PlanD& P, const BatchD& B, const int32_t* list, int32_t count, int32_t b0, int32_t nbc,
                   const double* kval, int32_t max_w) {
   static const bool force_big = std::getenv("HYMLS_MI_FACTOR_LDS") && std::atoi(std::getenv("HYMLS_MI_FACTOR_LDS")) > 3072;   // (A/B switch)
-  const bool small = !force_big && max_w * max_w + max_w <= 3072;
+  const bool small = !force_big && max_w * max_w + 2 * max_w <= 3072;
   if (count <= 0 || nbc <= 0) return;
   for (int s0 = 0; s0 < nbc; s0 += 65535) {
     const int ns = std::min(65535, nbc - s0);
@@ -704,7 +727,7 @@ __global__ void k_big_extend_add(PlanD P, BatchD B, FrontD F, FrontD Cf) {
 __global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64_t ld, int64_t strideA, int wk,
                                                   double* __restrict__ slab0, int64_t lds, int64_t strideS,
                                                   double* __restrict__ tmp0, int64_t strideT, int32_t* flag) {
-  extern __shared__ double S[];          // wk x wk block (column-major) + wk work vector
+  extern __shared__ double S[];          // wk x wk block (column-major) + 2 wk work vector
   __shared__ int s_bad;
   __shared__ unsigned long long s_m0, s_ml, s_mu;
   const int tid = threadIdx.x, slot = blockIdx.x, w = wk;
@@ -716,64 +739,8 @@ __global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64
   if (tid == 0) { s_bad = 0; s_m0 = 0; s_ml = 0; s_mu = 0; }
   for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + ld * (t / w)];
   __syncthreads();
-  block_absmax(S, w, w, true, true, &s_m0);
-  // right-looking LU
-  for (int k = 0; k < w; k++) {
-    const double piv = S[k + w * k];
-    if (tid == 0 && (piv == 0.0 || !isfinite(piv))) s_bad = 1;
-    const double ip = 1.0 / piv;
-    __syncthreads();
-    for (int i = k + 1 + tid; i < w; i += FT) S[i + w * k] *= ip;
-    __syncthreads();
-    const int rem = w - k - 1;
-    for (int t = tid; t < rem * rem; t += FT) {
-      const int i = k + 1 + t % rem, j = k + 1 + t / rem;
-      S[i + w * j] -= S[i + w * k] * S[k + w * j];
-    }
-    __syncthreads();
-  }
-  block_absmax(S, w, w, true, false, &s_ml);
-  block_absmax(S, w, w, false, true, &s_mu);
-  __syncthreads();
-  if (tid == 0 && (__longlong_as_double((long long)s_ml) > GROWTH_LIMIT ||
-                   __longlong_as_double((long long)s_mu) > GROWTH_LIMIT * __longlong_as_double((long long)s_m0))) s_bad |= 2;
+  lds_lu_and_inverses(S, w, xv, &s_bad, &s_m0, &s_ml, &s_mu);
   if (s_bad && tid == 0) atomicOr(flag, s_bad);
-  // in-place inverse of the unit lower factor: columns from the last to the first,
-  // X[j+1:, j] = - X[j+1:, j+1:] * L[j+1:, j]   (X[j+1:, j+1:] already holds the inverse)
-  for (int j = w - 2; j >= 0; j--) {
-    for (int i = j + 1 + tid; i < w; i += FT) xv[i] = S[i + w * j];
-    __syncthreads();
-    for (int i = j + 1 + tid; i < w; i += FT) {
-      double s0 = xv[i] /* unit diagonal of X */, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int k = j + 1;
-      for (; k + 3 < i; k += 4) {
-        s0 += S[i + w * k] * xv[k]; s1 += S[i + w * (k + 1)] * xv[k + 1];
-        s2 += S[i + w * (k + 2)] * xv[k + 2]; s3 += S[i + w * (k + 3)] * xv[k + 3];
-      }
-      for (; k < i; k++) s0 += S[i + w * k] * xv[k];
-      S[i + w * j] = -((s0 + s1) + (s2 + s3));
-    }
-    __syncthreads();
-  }
-  // in-place inverse of the upper factor: columns from the first to the last,
-  // Y[j,j] = 1/U[j,j]; Y[0:j, j] = -Y[0:j, 0:j] * U[0:j, j] * Y[j,j]
-  for (int j = 0; j < w; j++) {
-    for (int i = tid; i < j; i += FT) xv[i] = S[i + w * j];
-    const double d = 1.0 / S[j + w * j];
-    __syncthreads();
-    for (int i = tid; i < j; i += FT) {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int k = i;
-      for (; k + 3 < j; k += 4) {
-        s0 += S[i + w * k] * xv[k]; s1 += S[i + w * (k + 1)] * xv[k + 1];
-        s2 += S[i + w * (k + 2)] * xv[k + 2]; s3 += S[i + w * (k + 3)] * xv[k + 3];
-      }
-      for (; k < j; k++) s0 += S[i + w * k] * xv[k];
-      S[i + w * j] = -((s0 + s1) + (s2 + s3)) * d;
-    }
-    if (tid == 0) S[j + w * j] = d;
-    __syncthreads();
-  }
   for (int t = tid; t < w * w; t += FT) {
     const int i = t % w, j = t / w;
     const double v = S[t];
@@ -942,7 +909,7 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
                       int32_t nbc, const double* kval) {
   if (nbc <= 0) return;
   if (!ctx().big_attr_set) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_big_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((PIECE * PIECE + PIECE) * sizeof(double))));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_big_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((PIECE * PIECE + 2 * PIECE) * sizeof(double))));
     ctx().big_attr_set = true;
   }
   if (nbc > 65535) throw Error(-3, "too many batch members for the big-front path");
@@ -969,7 +936,7 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     const int off = k * PIECE, wk = std::min(PIECE, w - off), rk = m - off - wk;
     double* Ak = A0 + off * (ld + 1);
     double* tk = B.tmp + (int64_t)k * 2 * PIECE * PIECE;
-    hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(FT), (size_t)(wk * wk + wk) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
+    hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(FT), (size_t)(wk * wk + 2 * wk) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
     launch_check();
     if (rk > 0) {
       hipLaunchKernelGGL(k_big_trmm_u, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);

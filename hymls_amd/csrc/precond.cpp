@@ -938,6 +938,7 @@ void LevelSolver::build_classes() {
     out.hash = H.h;
   };
   std::unordered_map<uint64_t, std::vector<int>> table;
+  std::vector<ivec> sd_src(nsd);
   const size_t first_new = cls_.size();
   constexpr int64_t CHUNK = 512;
   for (int64_t c0 = 0; c0 < (int64_t)my_sds_.size(); c0 += CHUNK) {
@@ -975,8 +976,9 @@ void LevelSolver::build_classes() {
       sd_cls_[s] = cid;
       sd_bidx_[s] = (int32_t)C.lu.members.size();
       C.lu.members.push_back(s);
-      // map the class's entry numbering (plan.ent_id refers to the extended CSR) onto this member
-      C.lu.h_src.insert(C.lu.h_src.end(), Pt.src.begin(), Pt.src.end());
+      // map the class's entry numbering (plan.ent_id refers to the extended CSR) onto this member: the lists are kept
+      // per subdomain and copied into the class arrays at the end, in parallel and without reallocation
+      sd_src[s].swap(Pt.src);
     }
     std::atomic<int> mismatch{0};
     parallel_for(c1 - c0, [&](int64_t k) {
@@ -988,6 +990,16 @@ void LevelSolver::build_classes() {
             C.mult == Pt.mult && C.lgptr == Pt.lgptr && C.key_extra == Pt.key_extra)) mismatch = 1;
     }, 1);
     HYMLS_CHECK(mismatch == 0, -3, "two different subdomain patterns share one 64-bit hash");
+  }
+  for (size_t c = first_new; c < cls_.size(); c++) {
+    Cls& C = *cls_[c];
+    const size_t ne = C.pat.col.size();
+    C.lu.h_src.resize(ne * C.lu.members.size());
+    parallel_for((int64_t)C.lu.members.size(), [&](int64_t b) {
+      ivec& v = sd_src[C.lu.members[b]];
+      std::copy(v.begin(), v.end(), C.lu.h_src.begin() + (size_t)b * ne);
+      ivec().swap(v);
+    }, 64);
   }
   // ---- pass 2: symbolic analysis of every class (independent: in parallel)
   parallel_for((int64_t)(cls_.size() - first_new), [&](int64_t k) {

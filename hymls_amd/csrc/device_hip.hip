@@ -399,10 +399,11 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
     const double piv = S[k + w * k];
     if (tid == 0 && (piv == 0.0 || !isfinite(piv))) *s_bad |= 1;
     const double ip = 1.0 / piv;
-    const int rem = w - k - 1;
-    for (int t = tid; t < rem * rem; t += nt) {
-      const int i = k + 1 + t % rem, j = k + 1 + t / rem;
-      S[i + w * j] -= (S[i + w * k] * ip) * S[k + w * j];
+    // a wave takes 64 consecutive rows of one column (no bank conflicts, no integer division), the waves take the columns in turn
+    const int ti = tid & 63, tj = tid >> 6, nw = nt >> 6;
+    for (int j = k + 1 + tj; j < w; j += nw) {
+      const double ukj = S[k + w * j];
+      for (int i = k + 1 + ti; i < w; i += 64) S[i + w * j] -= (S[i + w * k] * ip) * ukj;
     }
     __syncthreads();
   }
@@ -411,11 +412,17 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
     if (i > j) S[t] *= 1.0 / S[j + w * j];
   }
   __syncthreads();
-  block_absmax(S, w, w, true, false, s_ml);
   block_absmax(S, w, w, false, true, s_mu);
   __syncthreads();
-  if (tid == 0 && (__longlong_as_double((long long)*s_ml) > GROWTH_LIMIT ||
-                   __longlong_as_double((long long)*s_mu) > GROWTH_LIMIT * __longlong_as_double((long long)*s_m0))) *s_bad |= 2;
+  if (tid == 0) {
+    // growth factor max |u_ij| / max |a_ij| of this block (the multipliers alone say nothing: in a saddle-point block
+    // [a b; c 0] scaled like the reference's Stokes matrices they reach a / b^2 ~ 1e5 without any loss of accuracy)
+    const double m0 = __longlong_as_double((long long)*s_m0), mu = __longlong_as_double((long long)*s_mu);
+    const double rho = m0 > 0.0 ? mu / m0 : 0.0;
+    if (rho > GROWTH_LIMIT) *s_bad |= 2;
+    *s_ml = (unsigned long long)__double_as_longlong(rho);   // (handed to the caller: recorded next to the flag)
+  }
+  __syncthreads();
   // inverse of the unit lower factor, columns from the last to the first:
   // X[j+1:, j] = - X[j+1:, j+1:] * L[j+1:, j]   (X[j+1:, j+1:] already holds the inverse)
   double* xa = xv;
@@ -423,15 +430,20 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
   if (w >= 2) for (int i = w - 1 + tid; i < w; i += nt) xa[i] = S[i + w * (w - 2)];
   __syncthreads();
   for (int j = w - 2; j >= 0; j--) {
-    for (int i = j + 1 + tid; i < w; i += nt) {
-      double s0 = xa[i] /* unit diagonal of X */, s1 = 0.0, s2 = 0.0, s3 = 0.0;    // four chains instead of one of length i - j
-      int k = j + 1;
-      for (; k + 3 < i; k += 4) {
+    // two lanes per row split the dot product (both halves in four chains), combined by a lane shuffle
+    for (int p = tid; p < 2 * (w - j - 1); p += nt) {
+      const int i = j + 1 + (p >> 1), h = p & 1;
+      const int kmid = (j + 1 + i) >> 1, kb = h ? kmid : j + 1, ke = h ? i : kmid;
+      double s0 = h ? 0.0 : xa[i] /* unit diagonal of X */, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = kb;
+      for (; k + 3 < ke; k += 4) {
         s0 += S[i + w * k] * xa[k]; s1 += S[i + w * (k + 1)] * xa[k + 1];
         s2 += S[i + w * (k + 2)] * xa[k + 2]; s3 += S[i + w * (k + 3)] * xa[k + 3];
       }
-      for (; k < i; k++) s0 += S[i + w * k] * xa[k];
-      S[i + w * j] = -((s0 + s1) + (s2 + s3));
+      for (; k < ke; k++) s0 += S[i + w * k] * xa[k];
+      double sum = (s0 + s1) + (s2 + s3);
+      sum += __shfl_xor(sum, 1, 64);
+      if (!h) S[i + w * j] = -sum;
     }
     if (j > 0) for (int i = j + tid; i < w; i += nt) xb[i] = S[i + w * (j - 1)];   // the column of the next step
     __syncthreads();
@@ -443,15 +455,19 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
   __syncthreads();
   for (int j = 0; j < w; j++) {
     const double d = 1.0 / xa[j];
-    for (int i = tid; i < j; i += nt) {
+    for (int p = tid; p < 2 * j; p += nt) {
+      const int i = p >> 1, h = p & 1;
+      const int kmid = (i + j) >> 1, kb = h ? kmid : i, ke = h ? j : kmid;
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int k = i;
-      for (; k + 3 < j; k += 4) {
+      int k = kb;
+      for (; k + 3 < ke; k += 4) {
         s0 += S[i + w * k] * xa[k]; s1 += S[i + w * (k + 1)] * xa[k + 1];
         s2 += S[i + w * (k + 2)] * xa[k + 2]; s3 += S[i + w * (k + 3)] * xa[k + 3];
       }
-      for (; k < j; k++) s0 += S[i + w * k] * xa[k];
-      S[i + w * j] = -((s0 + s1) + (s2 + s3)) * d;
+      for (; k < ke; k++) s0 += S[i + w * k] * xa[k];
+      double sum = (s0 + s1) + (s2 + s3);
+      sum += __shfl_xor(sum, 1, 64);
+      if (!h) S[i + w * j] = -sum * d;
     }
     if (tid == 0) S[j + w * j] = d;
     if (j + 1 < w) for (int i = tid; i <= j + 1; i += nt) xb[i] = S[i + w * (j + 1)];
@@ -531,11 +547,15 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       }
       __syncthreads();
     }
-    block_absmax(A, m, w, true, false, &s_ml);
     block_absmax(A, m, w, false, true, &s_mu);
     __syncthreads();
-    if (tid == 0 && (__longlong_as_double((long long)s_ml) > GROWTH_LIMIT ||
-                     __longlong_as_double((long long)s_mu) > GROWTH_LIMIT * __longlong_as_double((long long)s_m0))) s_bad |= 2;
+    if (tid == 0) {
+      const double m0 = __longlong_as_double((long long)s_m0), mu = __longlong_as_double((long long)s_mu);
+      const double rho = m0 > 0.0 ? mu / m0 : 0.0;
+      if (rho > GROWTH_LIMIT) s_bad |= 2;
+      s_ml = (unsigned long long)__double_as_longlong(rho);
+    }
+    __syncthreads();
     // 3. triangular inverses into the factor slab: strictly lower = L11^{-1}, upper = U11^{-1}
     for (int t = tid; t < w; t += FT) {
       for (int i = t + 1; i < w; i++) {
@@ -551,7 +571,10 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       }
     }
   }
-  if (s_bad && tid == 0) atomicOr(B.flag, s_bad);
+  if (tid == 0) {
+    if (s_bad) atomicOr(B.flag, s_bad);
+    atomicMax((unsigned long long*)(B.flag + 2), s_ml);   // largest growth factor seen by this batch
+  }
   __threadfence_block();
   __syncthreads();
   tick(2);
@@ -740,7 +763,10 @@ __global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64
   for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + ld * (t / w)];
   __syncthreads();
   lds_lu_and_inverses(S, w, xv, &s_bad, &s_m0, &s_ml, &s_mu);
-  if (s_bad && tid == 0) atomicOr(flag, s_bad);
+  if (tid == 0) {
+    if (s_bad) atomicOr(flag, s_bad);
+    atomicMax((unsigned long long*)(flag + 2), s_ml);
+  }
   for (int t = tid; t < w * w; t += FT) {
     const int i = t % w, j = t / w;
     const double v = S[t];

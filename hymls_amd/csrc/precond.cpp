@@ -143,8 +143,8 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   sblock_need_ = with_sblock ? std::max<int64_t>(1, (int64_t)chunk * plan.nS * plan.nS) : 0;
   batch.scratch = nullptr; batch.sblock = nullptr;
   batch.contrib = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)contrib_nv * nb * plan.contrib_size) * sizeof(double)));
-  batch.flag = (int32_t*)keep(dev::alloc(sizeof(int32_t)));
-  dev::zero(batch.flag, sizeof(int32_t));
+  batch.flag = (int32_t*)keep(dev::alloc(4 * sizeof(int32_t)));   // [flag bits | pad | largest growth factor (double bits)]
+  dev::zero(batch.flag, 4 * sizeof(int32_t));
   h_fronts = fd;
   bool any_big = false, any_wide = false;
   for (auto& L : plan.big_levels) any_big |= !L.empty();
@@ -227,10 +227,11 @@ void BatchedLU::solve(double* x) const {
   }
 }
 
-int32_t BatchedLU::check_flag() const {
-  int32_t f = 0;
-  dev::d2h(&f, batch.flag, sizeof f);
-  return f;
+int32_t BatchedLU::check_flag(double* growth) const {
+  int32_t f[4] = {0, 0, 0, 0};
+  dev::d2h(f, batch.flag, sizeof f);
+  if (growth) std::memcpy(growth, f + 2, sizeof(double));
+  return f[0];
 }
 
 // ------------------------------------------------------------------ merged level-synchronous solve tables
@@ -379,9 +380,11 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   d_val_ = dev::upload(A.val);
   lu_->factor_chunk(d_val_, 0, 1);
   {
-    const int32_t f = lu_->check_flag();
+    double g = 0.0;
+    const int32_t f = lu_->check_flag(&g);
+    if (std::getenv("HYMLS_MI_VERBOSE")) std::fprintf(stderr, "[hymls_mi] coarse solver: largest element growth of a pivot block %.3g\n", g);
     HYMLS_CHECK((f & 1) == 0, -4, "coarse factorisation hit a zero or non-finite pivot");
-    HYMLS_CHECK((f & 2) == 0, -4, "coarse factorisation without pivoting is unstable for this matrix: element growth above 1e8");
+    HYMLS_CHECK((f & 2) == 0, -4, "coarse factorisation without pivoting is unstable for this matrix: element growth " + std::to_string(g) + " > 1e8");
   }
   d_perm_ = dev::upload(lu_->plan.perm);
   // the tree levels of one large system are launch-latency bound with one launch chain per level (assemble, panels,
@@ -1461,6 +1464,26 @@ const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
     ivec len = comm_->allgather(my_len);
     ivec colg = comm_->allgather(red_.col);
     if (tvn) glob_tv_ = comm_->allgather(*tvn);
+    {
+      // clusters of the rows = the subdomains that list the node (the last-level direct solver dissects along them);
+      // every rank contributes the lists of its rows and the centres of its subdomains, so that a sharded run orders
+      // the coarse system exactly like a one-rank run
+      ivec my_cnt(red_.n), my_clu;
+      for (int r = 0; r < red_.n; r++) {
+        const int k = direct_schur_ ? r : vs_[r];
+        for (int t = sep_sd_ptr_[k]; t < sep_sd_ptr_[k + 1]; t++) my_clu.push_back(sep_sd_[t]);
+        my_cnt[r] = sep_sd_ptr_[k + 1] - sep_sd_ptr_[k];
+      }
+      ivec cntg = comm_->allgather(my_cnt);
+      glob_clu_ = comm_->allgather(my_clu);
+      glob_clu_ptr_.assign(1, 0);
+      for (int32_t c : cntg) glob_clu_ptr_.push_back(glob_clu_ptr_.back() + c);
+      ivec my_ctr;
+      for (int sd : my_sds_) { my_ctr.push_back(sd); for (int a = 0; a < 3; a++) my_ctr.push_back(sd_center_[3 * (size_t)sd + a]); }
+      ivec ctr = comm_->allgather(my_ctr);
+      glob_sd_center_.assign(sd_center_.size(), 0);
+      for (size_t t = 0; t + 3 < ctr.size(); t += 4) for (int a = 0; a < 3; a++) glob_sd_center_[3 * (size_t)ctr[t] + a] = ctr[t + 1 + a];
+    }
     const int64_t N = (int64_t)glob_gids_.size();
     HYMLS_CHECK(N < (int64_t)1 << 31, -2, "reduced matrix too large for 32-bit row numbers");
     ivec row_of(ngid_, -1);     // gid -> global row
@@ -1523,7 +1546,6 @@ void LevelSolver::build_handoff(const ivec& next_owned) {
 
 void LevelSolver::compute() {
   HYMLS_CHECK(initialized_, -1, "level not initialized");
-  const bool dist = comm_->distributed();
   const bool verbose = std::getenv("HYMLS_MI_VERBOSE") != nullptr;
   double t0 = wall();
   auto lap = [&](const char* what) {
@@ -1544,7 +1566,7 @@ void LevelSolver::compute() {
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
     if (side) dev::use_stream(1 + (int)(c % dev::NSIDE));
-    dev::zero(C.lu.batch.flag, sizeof(int32_t));
+    dev::zero(C.lu.batch.flag, 4 * sizeof(int32_t));
     const int nb = (int)C.lu.members.size();
     for (int b0 = 0; b0 < nb; b0 += C.lu.chunk) {
       const int nbc = std::min(C.lu.chunk, nb - b0);
@@ -1564,12 +1586,14 @@ void LevelSolver::compute() {
   }
   if (side) dev::join_streams();
   int32_t bad = 0, grown = 0;
-  for (auto& cp : cls_) { const int32_t f = cp->lu.check_flag(); bad |= (f & 1); grown |= (f & 2) >> 1; }
+  double growth = 0.0;
+  for (auto& cp : cls_) { double g = 0.0; const int32_t f = cp->lu.check_flag(&g); bad |= (f & 1); grown |= (f & 2) >> 1; growth = std::max(growth, g); }
+  if (verbose) std::fprintf(stderr, "[hymls_mi] rank %d level %d compute: largest element growth of a pivot block %.3g\n", comm_->rank, level_, growth);
   // (collective: every rank has to reach the exchanges below, so errors are agreed on first)
   HYMLS_CHECK(comm_->allsum(bad) == 0, -4, "subdomain factorisation hit a zero or non-finite pivot (level " +
                                                std::to_string(level_) + ")");
-  HYMLS_CHECK(comm_->allsum(grown) == 0, -4, "subdomain factorisation without pivoting is unstable for this matrix: element growth "
-                                             "above 1e8 (level " + std::to_string(level_) + "); the factor would be inaccurate");
+  HYMLS_CHECK(comm_->allsum(grown) == 0, -4, "subdomain factorisation without pivoting is unstable for this matrix: element growth " +
+                                             std::to_string(growth) + " > 1e8 (level " + std::to_string(level_) + "); the factor would be inaccurate");
   lap("factor + transform + extract");
   compute_border();
   exchange_records();
@@ -1584,8 +1608,7 @@ void LevelSolver::compute() {
     next_.reset();
     next_level_ = nullptr;
     next_is_direct_ = true;
-    if (dist) next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, nullptr, nullptr, nullptr, bm_ > 0));
-    else next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &sep_sd_ptr_, &sep_sd_, &sd_center_, bm_ > 0));
+    next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &glob_clu_ptr_, &glob_clu_, &glob_sd_center_, bm_ > 0));
     build_handoff(next_gids);
     set_next_border();
     return;
@@ -1640,16 +1663,7 @@ void LevelSolver::compute() {
   } else {
     next_level_ = nullptr;
     next_is_direct_ = true;
-    if (dist) {
-      next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, nullptr, nullptr, nullptr, bm_ > 0));
-    } else {
-      ivec cp(1, 0), cl;
-      for (int g = 0; g < ng; g++) {
-        for (int t = sep_sd_ptr_[vs_[g]]; t < sep_sd_ptr_[vs_[g] + 1]; t++) cl.push_back(sep_sd_[t]);
-        cp.push_back((int32_t)cl.size());
-      }
-      next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &cp, &cl, &sd_center_, bm_ > 0));
-    }
+    next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &glob_clu_ptr_, &glob_clu_, &glob_sd_center_, bm_ > 0));
     build_handoff(next_gids);
     set_next_border();
     lap("coarse solver");

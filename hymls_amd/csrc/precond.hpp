@@ -51,7 +51,7 @@ struct BatchedLU {
   void bind_scratch();            // point batch.scratch / sblock / tmp into the shared setup arena
   int64_t scratch_need_ = 0, sblock_need_ = 0, tmp_need_ = 0;   // doubles   // after factor_chunk and after the separator block was read
   void solve(double* x) const;    // forward + backward, all members, in place
-  int32_t check_flag() const;
+  int32_t check_flag(double* growth = nullptr) const;   // flag bits (1 zero pivot, 2 growth) and the largest growth factor
 };
 
 // tables of the merged level-synchronous solve (device.hpp: solve_fwd_tasks / solve_bwd_tasks) for a set of batches
@@ -290,6 +290,7 @@ class LevelSolver : public Operator {
   int32_t* d_flag_ = nullptr;
   // the reduced matrix of all ranks (rows in rank order), rebuilt every Compute from the gathered values
   Csr glob_;
+  ivec glob_clu_ptr_, glob_clu_, glob_sd_center_;   // clusters (subdomains) of the rows of glob_, centres of all subdomains
   ivec glob_gids_;
   dvec glob_tv_;
   std::vector<int64_t> glob_perm_;      // gathered entry -> entry of glob_

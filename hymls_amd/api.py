@@ -72,6 +72,7 @@ def load_library(path=None):
         "hymls_mi_rccl_comm_destroy": (None, [C.c_void_p]),
         "hymls_mi_set_comm_rccl": (C.c_int, [H, C.c_void_p, C.c_int, C.c_int, C.c_int]),
         "hymls_mi_comm_selftest": (C.c_int, [H]),
+        "hymls_mi_invert_blocks": (C.c_int, [H, C.c_int32, C.c_int32, _F64P]),
         "hymls_mi_required_rows": (C.c_int, [H, _I64P, _I32P]),
         "hymls_mi_set_matrix_rows": (C.c_int, [H, C.c_int64, _I32P, _I32P, _I32P, _F64P]),
         "hymls_mi_owned_rows": (C.c_int, [H, _I64P, _I32P]),
@@ -257,6 +258,15 @@ class Preconditioner:
     def CommSelfTest(self):
         """collective: 0 if the transport of this sharded handle moved a stamped all-to-all correctly, else the error code"""
         return self._lib.hymls_mi_comm_selftest(self._h)
+
+    def InvertBlocks(self, blocks):
+        """in-place inverses of a stack of dense blocks, shape (nblk, nb, nb) (the separator-block step of Compute on its
+        own: Ifpack_DenseContainer in the reference, src/HYMLS_SchurPreconditioner.cpp:284-291)"""
+        B = np.asarray(blocks, dtype=np.float64)
+        assert B.ndim == 3 and B.shape[1] == B.shape[2]
+        cm = np.array(B.transpose(0, 2, 1), dtype=np.float64, order="C", copy=True)     # column-major blocks (never the caller's memory)
+        self._check(self._lib.hymls_mi_invert_blocks(self._h, B.shape[1], B.shape[0], cm.ctypes.data_as(_F64P)))
+        return np.ascontiguousarray(cm.transpose(0, 2, 1))
 
     def RequiredRows(self):
         n = C.c_int64()

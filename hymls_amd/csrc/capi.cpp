@@ -195,6 +195,28 @@ int hymls_mi_comm_selftest(hymls_mi_t* h) {
   API_END(h)
 }
 
+int hymls_mi_invert_blocks(hymls_mi_t* h, int32_t nb, int32_t nblk, double* blocks) {
+  if (!h || (!blocks && nb > 0 && nblk > 0)) return -2;
+  API_BEGIN
+  HYMLS_CHECK(nb >= 0 && nblk >= 0, -2, "negative block order or count");
+  const size_t bytes = (size_t)nb * nb * nblk * sizeof(double);
+  if (bytes) {
+    double* d = (double*)dev::alloc(bytes);
+    int32_t* d_flag = (int32_t*)dev::alloc(sizeof(int32_t));
+    int32_t flag = 0;
+    try {
+      dev::h2d(d, blocks, bytes);
+      dev::zero(d_flag, sizeof(int32_t));
+      dev::dense_invert(nb, nblk, d, d_flag);
+      dev::d2h(&flag, d_flag, sizeof flag);
+      dev::d2h(blocks, d, bytes);
+    } catch (...) { dev::free(d); dev::free(d_flag); throw; }
+    dev::free(d); dev::free(d_flag);
+    HYMLS_CHECK(flag == 0, -4, "singular block");
+  }
+  API_END(h)
+}
+
 int hymls_mi_required_rows(hymls_mi_t* h, int64_t* n, int32_t* gids) {
   if (!h || !n) return -2;
   API_BEGIN

@@ -247,6 +247,9 @@ struct KeptD {
 void sblock_kept(const KeptD& K, const double* tv, const double* sblock, double* out, int64_t out_stride, int32_t nbc);
 // batched dense inverse with partial pivoting: nblk blocks of order nb (col-major), in place
 void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag);
+// true where dense_invert() takes the blocked (32 pivots at a time, matrix-core update) route: such groups are worth a
+// call of their own instead of a slot in the single-launch table of dense_invert_all()
+bool dense_invert_blocked_order(int32_t nb);
 // y[ids] = Binv x[ids] for nblk blocks of order nb; ids: [nblk][nb]
 void blocks_apply(int32_t nb, int32_t nblk, const double* binv, const int32_t* ids,
                   const double* x, double* y);

@@ -391,6 +391,8 @@ __device__ inline void block_absmax(const double* S, int64_t ld, int w, bool low
 // the whole workgroup with ONE barrier per elimination / inversion step (the multipliers are scaled after the loop; the
 // column an inversion step needs is copied into the other half of xv during the step before).  xv: 2 w doubles.
 // Element growth is measured on the way (see block_absmax); s_bad |= 1 for a zero / non-finite pivot, |= 2 for growth.
+// LPR lanes share a row of an inversion step (2 for the 256-thread front kernels, 8 for the 1024-thread pivot pieces).
+template <int LPR>
 __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_bad, unsigned long long* s_m0,
                                            unsigned long long* s_ml, unsigned long long* s_mu) {
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -431,9 +433,9 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
   __syncthreads();
   for (int j = w - 2; j >= 0; j--) {
     // two lanes per row split the dot product (both halves in four chains), combined by a lane shuffle
-    for (int p = tid; p < 2 * (w - j - 1); p += nt) {
-      const int i = j + 1 + (p >> 1), h = p & 1;
-      const int kmid = (j + 1 + i) >> 1, kb = h ? kmid : j + 1, ke = h ? i : kmid;
+    for (int p = tid; p < LPR * (w - j - 1); p += nt) {
+      const int i = j + 1 + p / LPR, h = p % LPR;
+      const int len = i - (j + 1), kb = j + 1 + (len * h) / LPR, ke = j + 1 + (len * (h + 1)) / LPR;
       double s0 = h ? 0.0 : xa[i] /* unit diagonal of X */, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       int k = kb;
       for (; k + 3 < ke; k += 4) {
@@ -442,7 +444,8 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
       }
       for (; k < ke; k++) s0 += S[i + w * k] * xa[k];
       double sum = (s0 + s1) + (s2 + s3);
-      sum += __shfl_xor(sum, 1, 64);
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) sum += __shfl_xor(sum, o, 64);
       if (!h) S[i + w * j] = -sum;
     }
     if (j > 0) for (int i = j + tid; i < w; i += nt) xb[i] = S[i + w * (j - 1)];   // the column of the next step
@@ -455,9 +458,9 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
   __syncthreads();
   for (int j = 0; j < w; j++) {
     const double d = 1.0 / xa[j];
-    for (int p = tid; p < 2 * j; p += nt) {
-      const int i = p >> 1, h = p & 1;
-      const int kmid = (i + j) >> 1, kb = h ? kmid : i, ke = h ? j : kmid;
+    for (int p = tid; p < LPR * j; p += nt) {
+      const int i = p / LPR, h = p % LPR;
+      const int len = j - i, kb = i + (len * h) / LPR, ke = i + (len * (h + 1)) / LPR;
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       int k = kb;
       for (; k + 3 < ke; k += 4) {
@@ -466,7 +469,8 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
       }
       for (; k < ke; k++) s0 += S[i + w * k] * xa[k];
       double sum = (s0 + s1) + (s2 + s3);
-      sum += __shfl_xor(sum, 1, 64);
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) sum += __shfl_xor(sum, o, 64);
       if (!h) S[i + w * j] = -sum * d;
     }
     if (tid == 0) S[j + w * j] = d;
@@ -528,7 +532,7 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     double* xv = lds + w * w;
     for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + (int64_t)m * (t / w)];
     __syncthreads();
-    lds_lu_and_inverses(S, w, xv, &s_bad, &s_m0, &s_ml, &s_mu);
+    lds_lu_and_inverses<2>(S, w, xv, &s_bad, &s_m0, &s_ml, &s_mu);
     for (int t = tid; t < w * w; t += FT) Lp[(t % w) + ld * (t / w)] = S[t];
   } else {
     // 2. LU (no pivoting) of the w x w pivot block in global memory (wide pivot blocks)
@@ -743,11 +747,12 @@ __global__ void k_big_extend_add(PlanD P, BatchD B, FrontD F, FrontD Cf) {
     A[rel[a] + (int64_t)m * rel[bb]] += Ac[(Cf.w + a) + (int64_t)mc * (Cf.w + bb)];
   }
 }
+constexpr int PIVOT_T = 1024;   // threads of a pivot-piece workgroup: the LDS block allows one workgroup per CU anyway
 // LU (no pivoting) of one wk x wk pivot piece (wk <= PIECE = 128), entirely in LDS, followed by the
 // in-place triangular inversions (unit-lower L and upper U share the block).  Results: packed into
 // the supernode's slab block (strictly lower = L^{-1}, upper = U^{-1}) and as dense copies Lf
 // (unit lower) / Uf (upper) for the panel products.  One workgroup per batch slot.
-__global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64_t ld, int64_t strideA, int wk,
+__global__ void __launch_bounds__(PIVOT_T) k_big_pivot(double* __restrict__ A0, int64_t ld, int64_t strideA, int wk,
                                                   double* __restrict__ slab0, int64_t lds, int64_t strideS,
                                                   double* __restrict__ tmp0, int64_t strideT, int32_t* flag) {
   extern __shared__ double S[];          // wk x wk block (column-major) + 2 wk work vector
@@ -760,14 +765,14 @@ __global__ void __launch_bounds__(FT) k_big_pivot(double* __restrict__ A0, int64
   double* Uf = Lf + (int64_t)PIECE * PIECE;
   double* xv = S + w * w;
   if (tid == 0) { s_bad = 0; s_m0 = 0; s_ml = 0; s_mu = 0; }
-  for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + ld * (t / w)];
+  for (int t = tid; t < w * w; t += PIVOT_T) S[t] = A[(t % w) + ld * (t / w)];
   __syncthreads();
-  lds_lu_and_inverses(S, w, xv, &s_bad, &s_m0, &s_ml, &s_mu);
+  lds_lu_and_inverses<PIVOT_T / 128>(S, w, xv, &s_bad, &s_m0, &s_ml, &s_mu);
   if (tid == 0) {
     if (s_bad) atomicOr(flag, s_bad);
     atomicMax((unsigned long long*)(flag + 2), s_ml);
   }
-  for (int t = tid; t < w * w; t += FT) {
+  for (int t = tid; t < w * w; t += PIVOT_T) {
     const int i = t % w, j = t / w;
     const double v = S[t];
     Sb[i + lds * j] = v;
@@ -962,7 +967,7 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     const int off = k * PIECE, wk = std::min(PIECE, w - off), rk = m - off - wk;
     double* Ak = A0 + off * (ld + 1);
     double* tk = B.tmp + (int64_t)k * 2 * PIECE * PIECE;
-    hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(FT), (size_t)(wk * wk + 2 * wk) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
+    hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(PIVOT_T), (size_t)(wk * wk + 2 * wk) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
     launch_check();
     if (rk > 0) {
       hipLaunchKernelGGL(k_big_trmm_u, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);
@@ -2599,77 +2604,306 @@ void sblock_kept(const KeptD& K, const double* tv, const double* sblock, double*
   }
 }
 
-// in-place Gauss-Jordan inversion with partial pivoting, one workgroup per block
-// one workgroup per block; `all` != nullptr: blocks of any order from a descriptor table (one launch for a
-// whole level, so that the few large blocks of the coarser levels run side by side), else nblk blocks of order nb0
-template <int BS>
-__global__ void __launch_bounds__(BS) k_dense_invert(int32_t nb0, double* __restrict__ blocks, const BlkD* __restrict__ all, int32_t* flag) {
-  extern __shared__ int piv[];   // nb ints, then reduction scratch
-  __shared__ double red_v[BS];
-  __shared__ int red_i[BS];
+// in-place Gauss-Jordan inversion with partial pivoting, one workgroup per block.
+// `all` != nullptr: blocks of any order from a descriptor table (one launch for a whole level), else nblk blocks of
+// order nb0.  INLDS: blocks of order <= lds_nb are copied into LDS (odd leading dimension) and inverted there, larger
+// ones are left to the !INLDS launch over the same table (which in turn skips the small ones when lds_nb > 0).
+// Three barriers per pivot: search (wave shuffles, then one LDS stage) | row interchange + scaling of the pivot row,
+// with the multiplier column copied to LDS | elimination, a wave per column, lanes down the rows.
+constexpr int GJ_LDS_NB = 88;   // 63.7 KiB of dynamic LDS at most
+template <int BS, bool INLDS>
+__global__ void __launch_bounds__(BS) k_dense_invert(int32_t nb0, double* __restrict__ blocks, const BlkD* __restrict__ all, int32_t* flag,
+                                                      int32_t lds_nb) {
+  extern __shared__ double dyn[];   // colk[nb] | piv[nb] (ints) | INLDS: the block
+  __shared__ double red_v[BS / 64];
+  __shared__ int red_i[BS / 64];
   const int nb = all ? all[blockIdx.x].nb : nb0;
-  double* A = all ? const_cast<double*>(all[blockIdx.x].binv) : blocks + (int64_t)blockIdx.x * nb * nb;
-  const int tid = threadIdx.x;
+  if (INLDS ? nb > lds_nb : nb <= lds_nb) return;
+  double* G = all ? const_cast<double*>(all[blockIdx.x].binv) : blocks + (int64_t)blockIdx.x * nb * nb;
+  double* colk = dyn;
+  int* piv = (int*)(dyn + nb);
+  const int ld = INLDS ? (nb | 1) : nb;
+  double* A = INLDS ? dyn + nb + (nb + 1) / 2 : G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x, nw = nt >> 6;
+  if (INLDS) {
+    for (int t = tid; t < nb * nb; t += nt) A[(t % nb) + ld * (t / nb)] = G[t];
+    __syncthreads();
+  }
   for (int k = 0; k < nb; k++) {
-    // pivot search in column k, rows k..nb-1
+    // pivot search in column k, rows k..nb-1: largest modulus, the first of equals
     double best = -1.0; int bi = k;
-    for (int i = k + tid; i < nb; i += blockDim.x) { const double a = fabs(A[i + (int64_t)nb * k]); if (a > best) { best = a; bi = i; } }
-    red_v[tid] = best; red_i[tid] = bi;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-      if (tid < s) {
-        if (red_v[tid + s] > red_v[tid] || (red_v[tid + s] == red_v[tid] && red_i[tid + s] < red_i[tid])) { red_v[tid] = red_v[tid + s]; red_i[tid] = red_i[tid + s]; }
-      }
-      __syncthreads();
+    for (int i = k + tid; i < nb; i += nt) { const double a = fabs(A[i + (int64_t)ld * k]); if (a > best) { best = a; bi = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    const int p = red_i[0];
-    const double pv = red_v[0];
+    if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
     __syncthreads();
-    if (!(pv > 0.0) || !isfinite(pv)) { if (tid == 0) atomicExch(flag, 1); return; }
+    double pv = red_v[0]; int p = red_i[0];
+    for (int q = 1; q < nw; q++) {
+      const double ov = red_v[q]; const int oi = red_i[q];
+      if (ov > pv || (ov == pv && oi < p)) { pv = ov; p = oi; }
+    }
+    if (!(pv > 0.0) || !isfinite(pv)) { if (tid == 0) atomicExch(flag, 1); return; }   // (the same for every thread)
+    const double ip = 1.0 / A[p + (int64_t)ld * k];
+    // multiplier column (after the interchange, pivot row excluded); column k itself is rewritten in the elimination
+    for (int i = tid; i < nb; i += nt) colk[i] = i == k ? 0.0 : A[(i == p ? k : i) + (int64_t)ld * k];
     if (tid == 0) piv[k] = p;
-    if (p != k)
-      for (int j = tid; j < nb; j += blockDim.x) { const double t = A[k + (int64_t)nb * j]; A[k + (int64_t)nb * j] = A[p + (int64_t)nb * j]; A[p + (int64_t)nb * j] = t; }
+    // rows k and p change places, the new row k is scaled by 1 / pivot
+    for (int j = tid; j < nb; j += nt)
+      if (j != k) {
+        const double akj = A[k + (int64_t)ld * j], apj = A[p + (int64_t)ld * j];
+        A[k + (int64_t)ld * j] = apj * ip;
+        if (p != k) A[p + (int64_t)ld * j] = akj;
+      }
     __syncthreads();
-    const double ip = 1.0 / A[k + (int64_t)nb * k];
-    __syncthreads();
-    if (tid == 0) A[k + (int64_t)nb * k] = 1.0;
-    __syncthreads();
-    for (int j = tid; j < nb; j += blockDim.x) A[k + (int64_t)nb * j] *= ip;
-    __syncthreads();
-    // eliminate column k from every other row; column k itself is rewritten afterwards
-    for (int64_t t = tid; t < (int64_t)nb * nb; t += blockDim.x) {
-      const int i = (int)(t % nb), j = (int)(t / nb);
-      if (i == k || j == k) continue;
-      A[i + (int64_t)nb * j] -= A[i + (int64_t)nb * k] * A[k + (int64_t)nb * j];
-    }
-    __syncthreads();
-    {
-      const double akk = A[k + (int64_t)nb * k];
-      for (int i = tid; i < nb; i += blockDim.x)
-        if (i != k) A[i + (int64_t)nb * k] = -A[i + (int64_t)nb * k] * akk;
+    for (int j = wave; j < nb; j += nw) {
+      double* cj = A + (int64_t)ld * j;
+      if (j == k) {
+        for (int i = lane; i < nb; i += 64) cj[i] = i == k ? ip : -colk[i] * ip;
+      } else {
+        const double r = cj[k];
+        for (int i = lane; i < nb; i += 64) cj[i] -= colk[i] * r;     // (colk[k] = 0: the pivot row stays)
+      }
     }
     __syncthreads();
   }
   for (int k = nb - 1; k >= 0; k--) {
     const int p = piv[k];
     if (p != k)
-      for (int i = tid; i < nb; i += blockDim.x) { const double t = A[i + (int64_t)nb * k]; A[i + (int64_t)nb * k] = A[i + (int64_t)nb * p]; A[i + (int64_t)nb * p] = t; }
+      for (int i = tid; i < nb; i += nt) { const double t = A[i + (int64_t)ld * k]; A[i + (int64_t)ld * k] = A[i + (int64_t)ld * p]; A[i + (int64_t)ld * p] = t; }
+    __syncthreads();
+  }
+  if (INLDS)
+    for (int t = tid; t < nb * nb; t += nt) G[t] = A[(t % nb) + ld * (t / nb)];
+}
+static size_t gj_dyn_bytes(int nb, bool inlds) {
+  return ((size_t)nb + (nb + 1) / 2 + (inlds ? (size_t)(nb | 1) * nb : 0)) * sizeof(double);
+}
+// ---- blocked Gauss-Jordan inversion of the large separator blocks (orders of several hundred on the coarser levels) ----
+// The scalar kernel above streams a whole block through one workgroup once per pivot: nb^3 x 16 B of traffic, HBM bound
+// for the whole chip.  Here GJB = 32 pivots are taken at a time:
+//   k_gj_panel       partial pivoting LU of the panel (rows >= kb of columns kb .. kb+31), one row per thread IN REGISTERS,
+//                    pivot row broadcast through LDS; leaves the pivot list, Inv = (A_KK)^{-1} of the permuted pivot rows,
+//                    W = the permuted panel with its pivot rows zeroed, and zeroes the panel columns of the block;
+//   k_gj_swap_scale  one thread per column: the panel's row interchanges, then the pivot rows A_K <- R = Inv A_K
+//                    (for the panel columns themselves: A_KK <- Inv);
+//   gemm_f64         A <- A - W R on the matrix cores (every row except the pivot rows, all columns: the panel columns
+//                    become -A_OK Inv, as the in-place Gauss-Jordan step does one column at a time);
+//   k_gj_unpermute   the column interchanges in reverse order at the end.
+// Same pivot candidates as the scalar kernel (rows not yet used as pivots), chosen panel by panel.
+constexpr int GJB = 32;
+constexpr int GJ_MAX = 1024;    // one row per thread
+// elimination step T of the panel LU (compile-time T: the row stays in registers), then step T + 1
+template <int T>
+__device__ __forceinline__ void gj_panel_steps(double (&a)[GJB], int bw, int kb, int i, bool active, int lane, int wave, int nw, int tid,
+                                               double* prow, double* krow, double* red_v, int* red_i, int* s_perm, int32_t* piv, int32_t* flag) {
+  if constexpr (T < GJB) {
+    constexpr int t = T;
+    if (t < bw) {
+      const int kr = kb + t;
+      double v = (active && i >= kr) ? fabs(a[t]) : -1.0;
+      if (v != v) v = INFINITY;   // a NaN must not hide behind the comparisons
+      int idx = i;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      }
+      if (lane == 0) { red_v[wave] = v; red_i[wave] = idx; }
+      __syncthreads();
+      double pv = red_v[0];
+      int p = red_i[0];
+      for (int q = 1; q < nw; q++) {
+        const double ov = red_v[q];
+        const int oi = red_i[q];
+        if (ov > pv || (ov == pv && oi < p)) { pv = ov; p = oi; }
+      }
+      if (tid == 0 && (!(pv > 0.0) || !isfinite(pv))) atomicExch(flag, 1);   // (the caller discards the blocks then)
+      if (i == p) {
+#pragma unroll
+        for (int c = 0; c < GJB; c++) prow[c] = a[c];
+      }
+      if (i == kr) {
+#pragma unroll
+        for (int c = 0; c < GJB; c++) krow[c] = a[c];
+      }
+      if (tid == 0) { piv[kr] = p; const int tmp = s_perm[kr]; s_perm[kr] = s_perm[p]; s_perm[p] = tmp; }
+      __syncthreads();
+      if (p != kr) {
+        if (i == p) {
+#pragma unroll
+          for (int c = 0; c < GJB; c++) a[c] = krow[c];
+        } else if (i == kr) {
+#pragma unroll
+          for (int c = 0; c < GJB; c++) a[c] = prow[c];
+        }
+      }
+      if (active && i > kr) {
+        const double l = a[t] / prow[t];
+        a[t] = l;
+#pragma unroll
+        for (int c = t + 1; c < GJB; c++) a[c] -= l * prow[c];
+      }
+    }
+    gj_panel_steps<T + 1>(a, bw, kb, i, active, lane, wave, nw, tid, prow, krow, red_v, red_i, s_perm, piv, flag);
+  }
+}
+__global__ void __launch_bounds__(1024) k_gj_panel(int nb, int kb, double* __restrict__ blocks, double* __restrict__ W0,
+                                                   double* __restrict__ Inv0, int32_t* __restrict__ piv0, int32_t* flag) {
+  __shared__ double prow[GJB], krow[GJB], red_v[16], LU[GJB * GJB], X[GJB * GJB];
+  __shared__ int red_i[16], s_perm[GJ_MAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, i = tid;
+  double* A = blocks + (int64_t)blockIdx.x * nb * nb;
+  double* W = W0 + (int64_t)blockIdx.x * nb * GJB;
+  double* Inv = Inv0 + (int64_t)blockIdx.x * GJB * GJB;
+  int32_t* piv = piv0 + (int64_t)blockIdx.x * nb;
+  const int bw = min(GJB, nb - kb);
+  const bool have = i < nb, active = have && i >= kb;
+  double a[GJB];
+#pragma unroll
+  for (int c = 0; c < GJB; c++) a[c] = (have && c < bw) ? A[i + (int64_t)nb * (kb + c)] : 0.0;
+  if (have) s_perm[i] = i;
+  for (int t = tid; t < GJB * GJB; t += blockDim.x) LU[t] = 0.0;
+  __syncthreads();
+  gj_panel_steps<0>(a, bw, kb, i, active, lane, wave, nw, tid, prow, krow, red_v, red_i, s_perm, piv, flag);
+  // pivot rows: L11 \ U11 of the permuted panel -> Inv = U11^{-1} L11^{-1}, one column per thread
+  if (active && i < kb + bw) {
+#pragma unroll
+    for (int c = 0; c < GJB; c++) if (c < bw) LU[(i - kb) + GJB * c] = a[c];
+  }
+  __syncthreads();
+  if (tid < GJB) {
+    const int j = tid;
+    if (j < bw) {
+      for (int r = 0; r < bw; r++) {
+        double sum = r == j ? 1.0 : 0.0;
+        for (int q = 0; q < r; q++) sum -= LU[r + GJB * q] * X[q * GJB + j];
+        X[r * GJB + j] = sum;
+      }
+      for (int r = bw - 1; r >= 0; r--) {
+        double sum = X[r * GJB + j];
+        for (int q = r + 1; q < bw; q++) sum -= LU[r + GJB * q] * X[q * GJB + j];
+        X[r * GJB + j] = sum / LU[r + GJB * r];
+      }
+    }
+    for (int r = 0; r < GJB; r++) Inv[r + GJB * j] = (r < bw && j < bw) ? X[r * GJB + j] : 0.0;
+  }
+  // W: the panel in its permuted row order (the block itself still holds the original panel), pivot rows zero
+  if (have) {
+    const int src = s_perm[i];
+#pragma unroll
+    for (int c = 0; c < GJB; c++) a[c] = c < bw ? A[src + (int64_t)nb * (kb + c)] : 0.0;
+  }
+  __syncthreads();
+  if (have) {
+    const bool pivot_row = i >= kb && i < kb + bw;
+#pragma unroll
+    for (int c = 0; c < GJB; c++)
+      if (c < bw) { W[i + (int64_t)nb * c] = pivot_row ? 0.0 : a[c]; A[i + (int64_t)nb * (kb + c)] = 0.0; }
+  }
+}
+__global__ void __launch_bounds__(256) k_gj_swap_scale(int nb, int kb, double* __restrict__ blocks, const double* __restrict__ Inv0,
+                                                       const int32_t* __restrict__ piv0, double* __restrict__ R0) {
+  __shared__ double sInv[GJB * GJB];
+  __shared__ int sp[GJB];
+  const int tid = threadIdx.x, j = blockIdx.x * 256 + tid, bw = min(GJB, nb - kb);
+  double* A = blocks + (int64_t)blockIdx.y * nb * nb;
+  const double* Inv = Inv0 + (int64_t)blockIdx.y * GJB * GJB;
+  double* R = R0 + (int64_t)blockIdx.y * GJB * nb;
+  for (int t = tid; t < GJB * GJB; t += 256) sInv[t] = Inv[t];
+  if (tid < GJB) sp[tid] = tid < bw ? piv0[(int64_t)blockIdx.y * nb + kb + tid] : 0;
+  __syncthreads();
+  if (j >= nb) return;
+  double* col = A + (int64_t)nb * j;
+  double x[GJB];
+  if (j >= kb && j < kb + bw) {
+    // a panel column: the identity in the pivot rows before the scaling, so R = Inv e_(j - kb)
+#pragma unroll
+    for (int r = 0; r < GJB; r++) x[r] = sInv[r + GJB * (j - kb)];
+  } else {
+    for (int t = 0; t < bw; t++) {
+      const int p = sp[t];
+      if (p != kb + t) { const double tmp = col[kb + t]; col[kb + t] = col[p]; col[p] = tmp; }
+    }
+    double y[GJB];
+#pragma unroll
+    for (int t = 0; t < GJB; t++) y[t] = t < bw ? col[kb + t] : 0.0;
+#pragma unroll
+    for (int r = 0; r < GJB; r++) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < GJB; t += 2) { s0 += sInv[r + GJB * t] * y[t]; s1 += sInv[r + GJB * (t + 1)] * y[t + 1]; }
+      x[r] = s0 + s1;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < GJB; r++) {
+    R[r + GJB * j] = x[r];
+    if (r < bw) col[kb + r] = x[r];
+  }
+}
+__global__ void __launch_bounds__(256) k_gj_unpermute(int nb, double* __restrict__ blocks, const int32_t* __restrict__ piv0) {
+  double* A = blocks + (int64_t)blockIdx.x * nb * nb;
+  const int32_t* piv = piv0 + (int64_t)blockIdx.x * nb;
+  for (int k = nb - 1; k >= 0; k--) {
+    const int p = piv[k];
+    if (p != k)
+      for (int i = threadIdx.x; i < nb; i += blockDim.x) { const double t = A[i + (int64_t)nb * k]; A[i + (int64_t)nb * k] = A[i + (int64_t)nb * p]; A[i + (int64_t)nb * p] = t; }
     __syncthreads();
   }
 }
+static int gj_blocked_min() {
+  static const int v = std::getenv("HYMLS_MI_INVERT_BLOCKED_MIN") ? std::atoi(std::getenv("HYMLS_MI_INVERT_BLOCKED_MIN")) : 160;
+  return v;
+}
+static void dense_invert_blocked(int32_t nb, int32_t nblk, double* blocks, int32_t* flag) {
+  const size_t wbytes = (size_t)nblk * nb * GJB * sizeof(double), ibytes = (size_t)nblk * GJB * GJB * sizeof(double);
+  const size_t pbytes = (((size_t)nblk * nb * sizeof(int32_t)) + 255) / 256 * 256;
+  char* ws = (char*)shared_scratch(2 * wbytes + ibytes + pbytes);
+  double* W = (double*)ws;
+  double* R = (double*)(ws + wbytes);
+  double* Inv = (double*)(ws + 2 * wbytes);
+  int32_t* piv = (int32_t*)(ws + 2 * wbytes + ibytes);
+  const int threads = std::min(1024, (nb + 63) / 64 * 64);
+  for (int kb = 0; kb < nb; kb += GJB) {
+    const int bw = std::min(GJB, nb - kb);
+    hipLaunchKernelGGL(k_gj_panel, dim3(nblk), dim3(threads), 0, g_stream, nb, kb, blocks, W, Inv, piv, flag);
+    hipLaunchKernelGGL(k_gj_swap_scale, dim3((nb + 255) / 256, nblk), dim3(256), 0, g_stream, nb, kb, blocks, Inv, piv, R);
+    launch_check();
+    gemm_f64<1, 0, 0>(blocks, nb, (int64_t)nb * nb, W, nb, (int64_t)nb * GJB, R, GJB, (int64_t)GJB * nb, nb, nb, bw, nblk);
+  }
+  hipLaunchKernelGGL(k_gj_unpermute, dim3(nblk), dim3(256), 0, g_stream, nb, blocks, piv);
+  launch_check();
+}
+bool dense_invert_blocked_order(int32_t nb) { return nb >= gj_blocked_min() && nb <= GJ_MAX; }
 void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag) {
   if (nb <= 0 || nblk <= 0) return;
-  const int bs = nb <= 64 ? 64 : 256;
-  hipLaunchKernelGGL(k_dense_invert<256>, dim3(nblk), dim3(bs), (size_t)nb * sizeof(int), g_stream, nb, blocks, (const BlkD*)nullptr, flag);
+  if (dense_invert_blocked_order(nb)) {
+    for (int32_t b0 = 0; b0 < nblk; b0 += 65535) dense_invert_blocked(nb, std::min(65535, nblk - b0), blocks + (int64_t)b0 * nb * nb, flag);
+    return;
+  }
+  if (nb <= GJ_LDS_NB)
+    hipLaunchKernelGGL((k_dense_invert<256, true>), dim3(nblk), dim3(nb <= 16 ? 64 : 256), gj_dyn_bytes(nb, true), g_stream, nb, blocks, (const BlkD*)nullptr, flag, GJ_LDS_NB);
+  else if (nb > 256)
+    hipLaunchKernelGGL((k_dense_invert<1024, false>), dim3(nblk), dim3(1024), gj_dyn_bytes(nb, false), g_stream, nb, blocks, (const BlkD*)nullptr, flag, 0);
+  else
+    hipLaunchKernelGGL((k_dense_invert<256, false>), dim3(nblk), dim3(256), gj_dyn_bytes(nb, false), g_stream, nb, blocks, (const BlkD*)nullptr, flag, 0);
   launch_check();
 }
 void dense_invert_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, int32_t* flag) {
   if (nblk <= 0) return;
-  // a few large blocks (coarser levels): 1024 threads per block, the rank-1 updates are what takes the time
-  if (max_nb > 256 && nblk <= 4096)
-    hipLaunchKernelGGL(k_dense_invert<1024>, dim3(nblk), dim3(1024), (size_t)max_nb * sizeof(int), g_stream, 0, (double*)nullptr, blocks, flag);
-  else
-    hipLaunchKernelGGL(k_dense_invert<256>, dim3(nblk), dim3(256), (size_t)max_nb * sizeof(int), g_stream, 0, (double*)nullptr, blocks, flag);
+  // two launches over the same table: orders up to GJ_LDS_NB inside LDS, the others in global memory (1024 threads where
+  // blocks are large: the rank-1 updates take the time)
+  hipLaunchKernelGGL((k_dense_invert<256, true>), dim3(nblk), dim3(256), gj_dyn_bytes(std::min(max_nb, GJ_LDS_NB), true), g_stream, 0, (double*)nullptr,
+                     blocks, flag, GJ_LDS_NB);
+  if (max_nb > 256)
+    hipLaunchKernelGGL((k_dense_invert<1024, false>), dim3(nblk), dim3(1024), gj_dyn_bytes(max_nb, false), g_stream, 0, (double*)nullptr, blocks, flag, GJ_LDS_NB);
+  else if (max_nb > GJ_LDS_NB)
+    hipLaunchKernelGGL((k_dense_invert<256, false>), dim3(nblk), dim3(256), gj_dyn_bytes(max_nb, false), g_stream, 0, (double*)nullptr, blocks, flag, GJ_LDS_NB);
   launch_check();
 }
 

@@ -1296,12 +1296,12 @@ void LevelSolver::build_schur_setup() {
       // one descriptor per block, largest first, for the single-launch inversion; for the apply the large blocks
       // (coarser levels: orders of 1000+) are cut into 64-row tiles so that many waves share one block
       std::vector<dev::BlkD> bd, ba;
-      blk_max_nb_ = 0;
+      blk_max_nb_ = 0; blk_max_nb_inv_ = 0;
       const int tile_min = std::getenv("HYMLS_MI_BLOCK_TILE_MIN") ? std::atoi(std::getenv("HYMLS_MI_BLOCK_TILE_MIN")) : 128;
       for (auto& B : blocks_) {
         for (int q = 0; q < B.nblk; q++) {
           const dev::BlkD D{B.d_binv + (int64_t)q * B.nb * B.nb, B.d_ids + (int64_t)q * B.nb, B.nb, -1};
-          bd.push_back(D);
+          if (!dev::dense_invert_blocked_order(B.nb)) { bd.push_back(D); blk_max_nb_inv_ = std::max(blk_max_nb_inv_, B.nb); }
           if (B.nb <= tile_min) ba.push_back(D);
           else for (int r0 = 0; r0 < B.nb; r0 += 64) { dev::BlkD T = D; T.r0 = r0; ba.push_back(T); }
         }
@@ -1620,7 +1620,33 @@ void LevelSolver::compute() {
     const int64_t bl = (int64_t)B.nb * B.nb;
     dev::pull_sum_blocks(bl, B.nblk, B.d_pull_ptr, B.d_pull_base, d_ext_, B.d_binv);
   }
-  dev::dense_invert_all(n_blk_, d_blkd_, blk_max_nb_, d_flag_);
+  if (getenv("HYMLS_MI_BLOCK_STATS")) {
+    std::map<int, int> hist;
+    double cube = 0;
+    for (auto& B : blocks_) { hist[B.nb] += B.nblk; cube += (double)B.nblk * B.nb * B.nb * B.nb; }
+    fprintf(stderr, "level %d separator blocks: %d, max order %d, sum nb^3 %.3e;", level_, n_blk_, blk_max_nb_, cube);
+    for (auto& h : hist) fprintf(stderr, " %dx%d", h.second, h.first);
+    fprintf(stderr, "\n");
+  }
+  {
+    // the large blocks of the coarser levels group by group (blocked, matrix cores), spread over the side streams;
+    // everything else in one launch on the main stream meanwhile
+    bool any_big = false;
+    for (auto& B : blocks_) any_big = any_big || dev::dense_invert_blocked_order(B.nb);
+    struct MainStreamGuard { ~MainStreamGuard() { try { dev::use_stream(0); } catch (...) {} } } back_to_main;
+    if (any_big) {
+      dev::fork_streams();
+      int k = 0;
+      for (auto& B : blocks_)
+        if (dev::dense_invert_blocked_order(B.nb)) {
+          dev::use_stream(1 + (k++ % dev::NSIDE));
+          dev::dense_invert(B.nb, B.nblk, B.d_binv, d_flag_);
+        }
+      dev::use_stream(0);
+    }
+    dev::dense_invert_all(n_blk_, d_blkd_, blk_max_nb_inv_, d_flag_);
+    if (any_big) dev::join_streams();
+  }
   int32_t flag = 0;
   dev::d2h(&flag, d_flag_, sizeof flag);
   HYMLS_CHECK(comm_->allsum(flag != 0) == 0, -4,

@@ -278,7 +278,7 @@ class LevelSolver : public Operator {
   std::vector<BlockClass> blocks_;
   dev::BlkD* d_blkd_ = nullptr;   // all blocks (single-launch inversion)
   dev::BlkD* d_blka_ = nullptr;   // apply tasks: small blocks whole, large blocks in 64-row tiles
-  int32_t n_blk_ = 0, n_blk_apply_ = 0, blk_max_nb_ = 0;
+  int32_t n_blk_ = 0, n_blk_apply_ = 0, blk_max_nb_ = 0, blk_max_nb_inv_ = 0;   // (_inv_: largest order in the inversion table)
   // rows of the reduced (V-sum) matrix or of the full Schur complement owned here: pattern + pull lists
   Csr red_;                  // col = gid of the column node
   std::vector<int64_t> red_pull_ptr_, red_pull_idx_;

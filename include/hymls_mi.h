@@ -108,6 +108,10 @@ int hymls_mi_set_comm_rccl(hymls_mi_t* h, void* nccl_comm /* ncclComm_t */, int 
 /* collective check of the transport of a sharded handle (either kind): an uneven device all-to-all of stamped values on the
  * handle's stream and a host-side count exchange; 0 if this rank sent and received what it should. */
 int hymls_mi_comm_selftest(hymls_mi_t* h);
+/* the separator-block inversion on its own (the role of Ifpack_DenseContainer::Compute, dgetrf + dgetri, in the reference's
+ * src/HYMLS_SchurPreconditioner.cpp:284-291): nblk column-major blocks of order nb in host memory are inverted in place on
+ * the handle's device (partial pivoting; large orders take the blocked matrix-core route).  -4 for a singular block. */
+int hymls_mi_invert_blocks(hymls_mi_t* h, int32_t nb, int32_t nblk, double* blocks);
 /* the rows this rank has to be given: interiors and separators of its subdomains (the overlapping
  * row map of the reference).  Two-call protocol (gids == NULL: count only); ascending gids. */
 int hymls_mi_required_rows(hymls_mi_t* h, int64_t* n, int32_t* gids);

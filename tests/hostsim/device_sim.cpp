@@ -430,6 +430,7 @@ void sblock_extract(int32_t nS, int64_t npick, const int32_t* pick, const double
     for (int64_t k = 0; k < npick; k++) out[(int64_t)b * out_stride + k] = sblock[(int64_t)b * nS * nS + pick[k]];
 }
 
+bool dense_invert_blocked_order(int32_t) { return false; }
 void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag) {
   std::vector<double> W((size_t)nb * 2 * nb);
   for (int B = 0; B < nblk; B++) {

@@ -501,3 +501,40 @@ def test_c_abi_from_plain_c(gpu_lib, tmp_path):
                            "-L", os.path.join(root, "hymls_amd"), "-lhymls_mi", "-Wl,-rpath," + os.path.join(root, "hymls_amd"), "-lm"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "CAPI_SMOKE" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,nblk", [(1, 3), (10, 5), (64, 7), (88, 3), (100, 3), (160, 3), (191, 4), (392, 3), (791, 2), (1024, 1), (1100, 1)])
+def test_separator_block_inversion_gpu(gpu_lib, nb, nblk):
+    """hymls_mi_invert_blocks (Ifpack_DenseContainer::Compute in the reference, SchurPreconditioner.cpp:284-291): orders
+    >= 160 take the blocked Gauss-Jordan route (32 pivots per panel, matrix-core update), orders that are no multiple of
+    32 included; 1100 exceeds its one-row-per-thread limit and takes the scalar kernel.  Checked against LAPACK (numpy):
+    |X A - I| small, and blocks that NEED the row interchanges (zero diagonal) are inverted as well."""
+    A, tv = problem("Laplace", 8)
+    P = product_prec(A, tv, xml_params("Laplace", 8, 4, 0), gpu_lib)
+    rng = np.random.default_rng(nb)
+    B = rng.uniform(-1, 1, (nblk, nb, nb))
+    B[0] += nb * np.eye(nb)                               # one diagonally dominant block (the separator blocks are)
+    if nblk > 1 and nb > 1:
+        B[1][np.arange(nb), np.arange(nb)] = 0.0          # zero diagonal: no LU without interchanges
+    if nblk > 2:
+        B[2] = 65536.0 * (np.diag(np.full(nb, 6.0)) - np.diag(np.ones(nb - 1), 1) - np.diag(np.ones(nb - 1), -1)) if nb > 1 else B[2]
+    X = P.InvertBlocks(B)
+    for q in range(nblk):
+        ref = np.linalg.inv(B[q])
+        cond = np.linalg.cond(B[q])
+        assert np.abs(X[q] - ref).max() <= 1e-13 * cond * np.abs(ref).max(), (nb, q, cond)
+        assert np.abs(X[q] @ B[q] - np.eye(nb)).max() <= 1e-13 * cond
+
+
+@pytest.mark.gpu
+def test_singular_separator_block_is_reported_gpu(gpu_lib):
+    from hymls_amd.api import HymlsError
+    A, tv = problem("Laplace", 8)
+    P = product_prec(A, tv, xml_params("Laplace", 8, 4, 0), gpu_lib)
+    for nb in (40, 200):
+        B = np.random.default_rng(1).uniform(-1, 1, (2, nb, nb))
+        B[1][:, 7] = 0.0
+        with pytest.raises(HymlsError) as e:
+            P.InvertBlocks(B)
+        assert e.value.code == -4

@@ -291,3 +291,16 @@ def test_retain_nodes_stokes_2d(hostsim_lib):
     assert [s[1] for s in P.level_sizes()] == [s[1] for s in O.level_sizes()]
     b = np.random.default_rng(3).uniform(-1, 1, A.shape[0])
     assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-9
+
+
+def test_separator_block_inversion_hostsim(hostsim_lib):
+    """hymls_mi_invert_blocks through the C ABI on the simulator (the scalar Gauss-Jordan of the device interface)."""
+    A, tv = problem("Laplace", 8)
+    P = product_prec(A, tv, xml_params("Laplace", 8, 4, 0), hostsim_lib)
+    rng = np.random.default_rng(3)
+    B = rng.uniform(-1, 1, (3, 37, 37))
+    B[1][np.arange(37), np.arange(37)] = 0.0
+    X = P.InvertBlocks(B)
+    for q in range(3):
+        assert np.abs(X[q] @ B[q] - np.eye(37)).max() <= 1e-12 * np.linalg.cond(B[q])
+    assert P.InvertBlocks(np.zeros((0, 5, 5))).shape == (0, 5, 5)

@@ -314,6 +314,12 @@ void pull_sum_blocks(int64_t blen, int32_t nblk, const int64_t* ptr, const int64
 
 // ------------------------------------------------------------------ multifrontal factorisation
 constexpr int FT = 256;          // threads per front workgroup
+// (i, j) of element t = tid, tid + step, ... of an n-row column-major grid without a division per element
+struct Idx2 {
+  int i, j, di, dj, n;
+  __device__ Idx2(int t0, int nrows, int step) : i(t0 % nrows), j(t0 / nrows), di(step % nrows), dj(step / nrows), n(nrows) {}
+  __device__ void next() { i += di; j += dj; if (i >= n) { i -= n; j++; } }
+};
 constexpr int GEMM_KB = 16;
 
 // C(MxN) = beta*C - or + A(MxK) B(KxN), column-major, executed by the whole workgroup.
@@ -345,7 +351,7 @@ __device__ void wg_gemm(double* __restrict__ C, int64_t ldc, const double* __res
           Bs[kk * 64 + r] = (gn < N && gk < K) ? B[gk + ldb * gn] : 0.0;
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 2   // (fully unrolled this loop alone took k_factor_level to 248 VGPRs = ONE workgroup per CU; now 98: four)
         for (int kk = 0; kk < GEMM_KB; kk++) {
           double a[4], b[4];
 #pragma unroll
@@ -379,10 +385,8 @@ __device__ void wg_gemm(double* __restrict__ C, int64_t ldc, const double* __res
 constexpr double GROWTH_LIMIT = 1e8;
 __device__ inline void block_absmax(const double* S, int64_t ld, int w, bool lower, bool upper, unsigned long long* acc) {
   double m = 0.0;
-  for (int t = threadIdx.x; t < w * w; t += blockDim.x) {
-    const int i = t % w, j = t / w;
-    if ((i > j && lower) || (i <= j && upper)) m = fmax(m, fabs(S[i + ld * j]));
-  }
+  for (Idx2 q(threadIdx.x, w, blockDim.x); q.j < w; q.next())
+    if ((q.i > q.j && lower) || (q.i <= q.j && upper)) m = fmax(m, fabs(S[q.i + ld * q.j]));
   atomicMax(acc, (unsigned long long)__double_as_longlong(m));
 }
 
@@ -409,10 +413,8 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
     }
     __syncthreads();
   }
-  for (int t = tid; t < w * w; t += nt) {
-    const int i = t % w, j = t / w;
-    if (i > j) S[t] *= 1.0 / S[j + w * j];
-  }
+  for (Idx2 q(tid, w, nt); q.j < w; q.next())
+    if (q.i > q.j) S[q.i + w * q.j] *= 1.0 / S[q.j + w * q.j];
   __syncthreads();
   block_absmax(S, w, w, false, true, s_mu);
   __syncthreads();
@@ -515,10 +517,9 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     const int mc = Cf.w + Cf.ri + Cf.rs, rc = Cf.ri + Cf.rs;
     const double* Ac = sc + Cf.f_off;
     const int32_t* rel = P.rel + Cf.rel_off;
-    for (int64_t t = tid; t < (int64_t)rc * rc; t += FT) {
-      const int a = (int)(t % rc), bb = (int)(t / rc);
-      A[rel[a] + (int64_t)m * rel[bb]] += Ac[(Cf.w + a) + (int64_t)mc * (Cf.w + bb)];
-    }
+    if (rc > 0)
+      for (Idx2 q(tid, rc, FT); q.j < rc; q.next())
+        A[rel[q.i] + (int64_t)m * rel[q.j]] += Ac[(Cf.w + q.i) + (int64_t)mc * (Cf.w + q.j)];
     __syncthreads();
   }
   tick(1);
@@ -530,10 +531,10 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     // 2+3 (LDS path): LU of the pivot block and in-place triangular inverses inside LDS
     double* S = lds;
     double* xv = lds + w * w;
-    for (int t = tid; t < w * w; t += FT) S[t] = A[(t % w) + (int64_t)m * (t / w)];
+    for (Idx2 q(tid, w, FT); q.j < w; q.next()) S[q.i + w * q.j] = A[q.i + (int64_t)m * q.j];
     __syncthreads();
     lds_lu_and_inverses<2>(S, w, xv, &s_bad, &s_m0, &s_ml, &s_mu);
-    for (int t = tid; t < w * w; t += FT) Lp[(t % w) + ld * (t / w)] = S[t];
+    for (Idx2 q(tid, w, FT); q.j < w; q.next()) Lp[q.i + ld * q.j] = S[q.i + w * q.j];
   } else {
     // 2. LU (no pivoting) of the w x w pivot block in global memory (wide pivot blocks)
     block_absmax(A, m, w, true, true, &s_m0);
@@ -588,10 +589,10 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       const int cb = max(1, LD / w);
       for (int j0 = 0; j0 < r; j0 += cb) {
         const int nc = min(cb, r - j0);
-        for (int t = tid; t < w * nc; t += FT) lds[t] = A[(t % w) + (int64_t)m * (w + j0 + t / w)];
+        for (Idx2 q(tid, w, FT); q.j < nc; q.next()) lds[q.i + w * q.j] = A[q.i + (int64_t)m * (w + j0 + q.j)];
         __syncthreads();
-        for (int t = tid; t < w * nc; t += FT) {
-          const int i = t % w, j = t / w;
+        for (Idx2 q(tid, w, FT); q.j < nc; q.next()) {
+          const int i = q.i, j = q.j;
           double s0 = lds[i + w * j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
           int k = 0;
           for (; k + 3 < i; k += 4) {
@@ -610,10 +611,10 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
       const int rb = max(1, LD / w);
       for (int i0 = 0; i0 < r; i0 += rb) {
         const int nr = min(rb, r - i0);
-        for (int t = tid; t < nr * w; t += FT) lds[t] = A[(w + i0 + t % nr) + (int64_t)m * (t / nr)];
+        for (Idx2 q(tid, nr, FT); q.j < w; q.next()) lds[q.i + nr * q.j] = A[(w + i0 + q.i) + (int64_t)m * q.j];
         __syncthreads();
-        for (int t = tid; t < nr * w; t += FT) {
-          const int i = t % nr, j = t / nr;
+        for (Idx2 q(tid, nr, FT); q.j < w; q.next()) {
+          const int i = q.i, j = q.j;
           double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
           int k = 0;
           for (; k + 3 <= j; k += 4) {
@@ -632,8 +633,8 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
     tick(5);
     // 7. solve panels: PL = L21_int L11^{-1}, QU = U11^{-1} U12_int
     if (ri > 0) {
-      for (int64_t t = tid; t < (int64_t)ri * w; t += FT) {
-        const int i = (int)(t % ri), k = (int)(t / ri);
+      for (Idx2 q(tid, ri, FT); q.j < w; q.next()) {
+        const int i = q.i, k = q.j;
         double s0 = A[(w + i) + (int64_t)m * k] /* unit diagonal of L11^{-1} */, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int j = k + 1;
         for (; j + 3 < w; j += 4) {
@@ -643,8 +644,8 @@ __global__ void __launch_bounds__(FT) k_factor_level(PlanD P, BatchD B, const in
         for (; j < w; j++) s0 += A[(w + i) + (int64_t)m * j] * Lp[j + ld * k];
         Lp[(w + i) + ld * k] = (s0 + s1) + (s2 + s3);
       }
-      for (int64_t t = tid; t < (int64_t)w * ri; t += FT) {
-        const int i = (int)(t % w), j = (int)(t / w);
+      for (Idx2 q(tid, w, FT); q.j < ri; q.next()) {
+        const int i = q.i, j = q.j;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int k = i;
         for (; k + 3 < w; k += 4) {
@@ -741,11 +742,9 @@ __global__ void k_big_extend_add(PlanD P, BatchD B, FrontD F, FrontD Cf) {
   const double* Ac = sc + Cf.f_off;
   const int m = F.w + F.ri + F.rs, mc = Cf.w + Cf.ri + Cf.rs, rc = Cf.ri + Cf.rs;
   const int32_t* rel = P.rel + Cf.rel_off;
-  const int64_t tot = (int64_t)rc * rc;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
-    const int a = (int)(t % rc), bb = (int)(t / rc);
-    A[rel[a] + (int64_t)m * rel[bb]] += Ac[(Cf.w + a) + (int64_t)mc * (Cf.w + bb)];
-  }
+  if (rc <= 0) return;
+  for (Idx2 q(blockIdx.x * blockDim.x + threadIdx.x, rc, gridDim.x * blockDim.x); q.j < rc; q.next())   // (rc^2 and the stride fit an int)
+    A[rel[q.i] + (int64_t)m * rel[q.j]] += Ac[(Cf.w + q.i) + (int64_t)mc * (Cf.w + q.j)];
 }
 constexpr int PIVOT_T = 1024;   // threads of a pivot-piece workgroup: the LDS block allows one workgroup per CU anyway
 // LU (no pivoting) of one wk x wk pivot piece (wk <= PIECE = 128), entirely in LDS, followed by the
@@ -765,16 +764,228 @@ __global__ void __launch_bounds__(PIVOT_T) k_big_pivot(double* __restrict__ A0, 
   double* Uf = Lf + (int64_t)PIECE * PIECE;
   double* xv = S + w * w;
   if (tid == 0) { s_bad = 0; s_m0 = 0; s_ml = 0; s_mu = 0; }
-  for (int t = tid; t < w * w; t += PIVOT_T) S[t] = A[(t % w) + ld * (t / w)];
+  for (Idx2 q(tid, w, PIVOT_T); q.j < w; q.next()) S[q.i + w * q.j] = A[q.i + ld * q.j];
   __syncthreads();
   lds_lu_and_inverses<PIVOT_T / 128>(S, w, xv, &s_bad, &s_m0, &s_ml, &s_mu);
   if (tid == 0) {
     if (s_bad) atomicOr(flag, s_bad);
     atomicMax((unsigned long long*)(flag + 2), s_ml);
   }
-  for (int t = tid; t < w * w; t += PIVOT_T) {
-    const int i = t % w, j = t / w;
-    const double v = S[t];
+  for (Idx2 q(tid, w, PIVOT_T); q.j < w; q.next()) {
+    const int i = q.i, j = q.j;
+    const double v = S[i + w * j];
+    Sb[i + lds * j] = v;
+    Lf[i + (int64_t)w * j] = i > j ? v : (i == j ? 1.0 : 0.0);
+    Uf[i + (int64_t)w * j] = i <= j ? v : 0.0;
+  }
+}
+// ---- the same pivot piece, blocked: 32 x 32 diagonal blocks are factored and inverted IN REGISTERS by one wave (a row per
+// lane, rows broadcast with v_readlane: no LDS traffic, no barriers), everything else is 16 x 16 x 4 FP64 MFMA tile products
+// between LDS operands.  The piece is padded with the identity to a multiple of 32.  Per diagonal block: LU (wave 0) |
+// L^{-1} (wave 0) and U^{-1} (wave 1) | panels U12 = L11^{-1} A12, L21 = A21 U11^{-1} | trailing update; then the inverses of
+// the block triangular factors from the last block column / row to the first through a 96 x 32 side buffer:
+// X21 = -X22 (L21 L11^{-1}), Y12 = -(U11^{-1} U12) Y22.  About 25 barriers instead of 384.
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int PB = 32;
+constexpr int PIVB_T = 512;
+constexpr int PIVB_LT = 96;   // rows of the side buffer (PIECE - PB)
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+// one 16 x 16 tile sum_k fa(i, k) fb(k, j), k = kb .. ke-1 (multiple of 4 apart); lane l supplies fa(l & 15, k0 + (l >> 4)) and
+// fb(k0 + (l >> 4), l & 15), result register r holds the entry (row (l >> 4) + 4 r, column l & 15)
+template <class FA, class FB>
+__device__ __forceinline__ d4 tile_mma(int kb, int ke, int lane, FA fa, FB fb) {
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = kb; k0 < ke; k0 += 4) {
+    const int k = k0 + (lane >> 4);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(lane & 15, k), fb(k, lane & 15), acc, 0, 0, 0);
+  }
+  return acc;
+}
+__global__ void __launch_bounds__(PIVB_T) k_big_pivot_blk(double* __restrict__ A0, int64_t ld, int64_t strideA, int wk,
+                                                          double* __restrict__ slab0, int64_t lds, int64_t strideS,
+                                                          double* __restrict__ tmp0, int64_t strideT, int32_t* flag) {
+  extern __shared__ double S[];          // W x W block (column-major, identity padded) + PIVB_LT x PB side buffer
+  __shared__ int s_bad;
+  __shared__ unsigned long long s_m0, s_mu;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwv = PIVB_T / 64, slot = blockIdx.x, w = wk;
+  const int W = (w + PB - 1) / PB * PB, nbk = W / PB;
+  double* A = A0 + (int64_t)slot * strideA;
+  double* Sb = slab0 + (int64_t)slot * strideS;
+  double* Lf = tmp0 + (int64_t)slot * strideT;
+  double* Uf = Lf + (int64_t)PIECE * PIECE;
+  double* T = S + W * W;
+  if (tid == 0) { s_bad = 0; s_m0 = 0; s_mu = 0; }
+  for (Idx2 q(tid, W, PIVB_T); q.j < W; q.next()) S[q.i + W * q.j] = (q.i < w && q.j < w) ? A[q.i + ld * q.j] : (q.i == q.j ? 1.0 : 0.0);
+  __syncthreads();
+  block_absmax(S, W, w, true, true, &s_m0);
+  double umax = 0.0;                     // largest |u_ij| this thread has produced
+  const int r = lane & 31;
+  for (int kblk = 0; kblk < nbk; kblk++) {
+    const int k0 = PB * kblk, rem = W - k0 - PB, ns = rem / 16;
+    double* D = S + k0 + W * k0;
+    // LU of the diagonal block: row r in the registers of lane r (both halves of the wave hold the same rows)
+    if (wave == 0) {
+      double a[PB];
+#pragma unroll
+      for (int c = 0; c < PB; c++) a[c] = D[r + W * c];
+#pragma unroll
+      for (int t = 0; t < PB; t++) {
+        const double piv = lane_bcast(a[t], t);
+        if (lane == 0 && (piv == 0.0 || !isfinite(piv))) s_bad |= 1;
+        const double l = a[t] * (1.0 / piv);
+        const bool below = r > t;
+        if (below) a[t] = l;
+#pragma unroll
+        for (int c = t + 1; c < PB; c++) { const double u = lane_bcast(a[c], t); if (below) a[c] -= l * u; }
+      }
+#pragma unroll
+      for (int c = 0; c < PB; c++) { if (c >= r && k0 + c < w) umax = fmax(umax, fabs(a[c])); /* (not the identity padding) */ if (lane < PB) D[r + W * c] = a[c]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // X = L^{-1} (unit lower): rows of X in lanes, row t is final when its turn comes
+      double a[PB], x[PB];
+#pragma unroll
+      for (int c = 0; c < PB; c++) { a[c] = c < r ? D[r + W * c] : 0.0; x[c] = c == r ? 1.0 : 0.0; }
+#pragma unroll
+      for (int t = 0; t < PB - 1; t++) {
+        const bool below = r > t;
+        const double l = a[t];
+#pragma unroll
+        for (int c = 0; c <= t; c++) { const double xt = lane_bcast(x[c], t); if (below) x[c] -= l * xt; }
+      }
+#pragma unroll
+      for (int c = 0; c < PB; c++) if (lane < PB && c < r) D[r + W * c] = x[c];
+    } else if (wave == 1) {
+      // Y = U^{-1}: from the last row to the first
+      double a[PB], y[PB];
+#pragma unroll
+      for (int c = 0; c < PB; c++) { a[c] = c >= r ? D[r + W * c] : 0.0; y[c] = c == r ? 1.0 : 0.0; }
+#pragma unroll
+      for (int t = PB - 1; t >= 0; t--) {
+        const double d = 1.0 / lane_bcast(a[t], t);
+        if (r == t) {
+#pragma unroll
+          for (int c = t; c < PB; c++) y[c] *= d;
+        }
+        const bool above = r < t;
+        const double u = a[t];
+#pragma unroll
+        for (int c = t; c < PB; c++) { const double yt = lane_bcast(y[c], t); if (above) y[c] -= u * yt; }
+      }
+#pragma unroll
+      for (int c = 0; c < PB; c++) if (lane < PB && c >= r) D[r + W * c] = y[c];
+    }
+    __syncthreads();
+    if (rem > 0) {
+      // panels, in place: a wave owns a strip of 16 columns of A12 (both row tiles) or 16 rows of A21 (both column tiles)
+      for (int task = wave; task < 2 * ns; task += nwv) {
+        if (task < ns) {
+          const int jc = k0 + PB + 16 * task;
+          auto fb = [&](int k, int j) { return S[k + W * (jc + j)]; };
+          d4 acc[2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int ib = k0 + 16 * h;
+            auto fa = [&](int i, int k) { const int gi = ib + i; const double v = S[gi + W * k]; return k > gi ? 0.0 : (k == gi ? 1.0 : v); };
+            acc[h] = tile_mma(k0, ib + 16, lane, fa, fb);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              S[(k0 + 16 * h + (lane >> 4) + 4 * q) + W * (jc + (lane & 15))] = acc[h][q];
+              umax = fmax(umax, fabs(acc[h][q]));
+            }
+        } else {
+          const int ir = k0 + PB + 16 * (task - ns);
+          auto fa = [&](int i, int k) { return S[(ir + i) + W * k]; };
+          d4 acc[2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int jb = k0 + 16 * h;
+            auto fb = [&](int k, int j) { const int gj = jb + j; return k > gj ? 0.0 : S[k + W * gj]; };
+            acc[h] = tile_mma(k0, jb + 16, lane, fa, fb);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) S[(ir + (lane >> 4) + 4 * q) + W * (k0 + 16 * h + (lane & 15))] = acc[h][q];
+        }
+      }
+      __syncthreads();
+      // trailing update A22 -= L21 U12
+      for (int task = wave; task < ns * ns; task += nwv) {
+        const int i0 = k0 + PB + 16 * (task % ns), j0 = k0 + PB + 16 * (task / ns);
+        auto fa = [&](int i, int k) { return S[(i0 + i) + W * k]; };
+        auto fb = [&](int k, int j) { return S[k + W * (j0 + j)]; };
+        const d4 acc = tile_mma(k0, k0 + PB, lane, fa, fb);
+#pragma unroll
+        for (int q = 0; q < 4; q++) S[(i0 + (lane >> 4) + 4 * q) + W * (j0 + (lane & 15))] -= acc[q];
+      }
+      __syncthreads();
+    }
+  }
+  // growth factor max |u_ij| / max |a_ij| of the piece (see lds_lu_and_inverses)
+  atomicMax(&s_mu, (unsigned long long)__double_as_longlong(umax));
+  __syncthreads();
+  if (tid == 0) {
+    const double m0 = __longlong_as_double((long long)s_m0), mu = __longlong_as_double((long long)s_mu);
+    const double rho = m0 > 0.0 ? mu / m0 : 0.0;
+    if (rho > GROWTH_LIMIT) s_bad |= 2;
+    if (s_bad) atomicOr(flag, s_bad);
+    atomicMax((unsigned long long*)(flag + 2), (unsigned long long)__double_as_longlong(rho));
+  }
+  // inverse of the block lower triangular L: block columns from the last but one to the first
+  for (int jb = nbk - 2; jb >= 0; jb--) {
+    const int c0 = PB * jb, r0 = c0 + PB, rem = W - r0, ns = rem / 16;
+    for (int task = wave; task < 2 * ns; task += nwv) {          // T = L21 L11^{-1}
+      const int i0 = r0 + 16 * (task % ns), tc = task / ns, jc = c0 + 16 * tc;
+      auto fa = [&](int i, int k) { return S[(i0 + i) + W * k]; };
+      auto fb = [&](int k, int j) { const int gj = jc + j; const double v = S[k + W * gj]; return k < gj ? 0.0 : (k == gj ? 1.0 : v); };
+      const d4 acc = tile_mma(jc, c0 + PB, lane, fa, fb);
+#pragma unroll
+      for (int q = 0; q < 4; q++) T[(i0 - r0 + (lane >> 4) + 4 * q) + PIVB_LT * (16 * tc + (lane & 15))] = acc[q];
+    }
+    __syncthreads();
+    for (int task = wave; task < 2 * ns; task += nwv) {          // X21 = -X22 T
+      const int i0 = r0 + 16 * (task % ns), tc = task / ns;
+      auto fa = [&](int i, int k) { const int gi = i0 + i; const double v = S[gi + W * k]; return k > gi ? 0.0 : (k == gi ? 1.0 : v); };
+      auto fb = [&](int k, int j) { return T[(k - r0) + PIVB_LT * (16 * tc + j)]; };
+      const d4 acc = tile_mma(r0, i0 + 16, lane, fa, fb);
+#pragma unroll
+      for (int q = 0; q < 4; q++) S[(i0 + (lane >> 4) + 4 * q) + W * (c0 + 16 * tc + (lane & 15))] = -acc[q];
+    }
+    __syncthreads();
+  }
+  // inverse of the block upper triangular U: block rows from the last but one to the first (side buffer 32 x rem, ld 32)
+  for (int jb = nbk - 2; jb >= 0; jb--) {
+    const int r0 = PB * jb, c0 = r0 + PB, rem = W - c0, ns = rem / 16;
+    for (int task = wave; task < 2 * ns; task += nwv) {          // T = U11^{-1} U12
+      const int tr = task % 2, j0 = c0 + 16 * (task / 2), ib = r0 + 16 * tr;
+      auto fa = [&](int i, int k) { const int gi = ib + i; return k < gi ? 0.0 : S[gi + W * k]; };
+      auto fb = [&](int k, int j) { return S[k + W * (j0 + j)]; };
+      const d4 acc = tile_mma(ib, r0 + PB, lane, fa, fb);
+#pragma unroll
+      for (int q = 0; q < 4; q++) T[(16 * tr + (lane >> 4) + 4 * q) + PB * (j0 - c0 + (lane & 15))] = acc[q];
+    }
+    __syncthreads();
+    for (int task = wave; task < 2 * ns; task += nwv) {          // Y12 = -T Y22
+      const int tr = task % 2, j0 = c0 + 16 * (task / 2);
+      auto fa = [&](int i, int k) { return T[(16 * tr + i) + PB * (k - c0)]; };
+      auto fb = [&](int k, int j) { const int gj = j0 + j; return k > gj ? 0.0 : S[k + W * gj]; };
+      const d4 acc = tile_mma(c0, j0 + 16, lane, fa, fb);
+#pragma unroll
+      for (int q = 0; q < 4; q++) S[(r0 + 16 * tr + (lane >> 4) + 4 * q) + W * (j0 + (lane & 15))] = -acc[q];
+    }
+    __syncthreads();
+  }
+  for (Idx2 q(tid, w, PIVB_T); q.j < w; q.next()) {
+    const int i = q.i, j = q.j;
+    const double v = S[i + W * j];
     Sb[i + lds * j] = v;
     Lf[i + (int64_t)w * j] = i > j ? v : (i == j ? 1.0 : 0.0);
     Uf[i + (int64_t)w * j] = i <= j ? v : 0.0;
@@ -788,10 +999,10 @@ __global__ void __launch_bounds__(256) k_big_trmm_u(double* __restrict__ A0, int
   double* A = A0 + (int64_t)slot * strideA;                 // points at the piece's diagonal block
   const double* Lf = tmp0 + (int64_t)slot * strideT;
   const int j0 = blockIdx.x * 8, nc = min(8, rk - j0);
-  for (int t = tid; t < w * nc; t += 256) st[t] = A[(t % w) + ld * (w + j0 + t / w)];
+  for (Idx2 q(tid, w, 256); q.j < nc; q.next()) st[q.i + w * q.j] = A[q.i + ld * (w + j0 + q.j)];
   __syncthreads();
-  for (int t = tid; t < w * nc; t += 256) {
-    const int i = t % w, j = t / w;
+  for (Idx2 q(tid, w, 256); q.j < nc; q.next()) {
+    const int i = q.i, j = q.j;
     double s0 = st[i + w * j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int k = 0;
     for (; k + 3 < i; k += 4) {
@@ -810,10 +1021,10 @@ __global__ void __launch_bounds__(256) k_big_trmm_l(double* __restrict__ A0, int
   double* A = A0 + (int64_t)slot * strideA;
   const double* Uf = tmp0 + (int64_t)slot * strideT + (int64_t)PIECE * PIECE;
   const int i0 = blockIdx.x * 8, nr = min(8, rk - i0);
-  for (int t = tid; t < nr * w; t += 256) st[t] = A[(w + i0 + t % nr) + ld * (t / nr)];
+  for (Idx2 q(tid, nr, 256); q.j < w; q.next()) st[q.i + nr * q.j] = A[(w + i0 + q.i) + ld * q.j];
   __syncthreads();
-  for (int t = tid; t < nr * w; t += 256) {
-    const int i = t % nr, j = t / nr;
+  for (Idx2 q(tid, nr, 256); q.j < w; q.next()) {
+    const int i = q.i, j = q.j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int k = 0;
     for (; k + 3 <= j; k += 4) {
@@ -832,7 +1043,6 @@ __global__ void __launch_bounds__(256) k_big_trmm_l(double* __restrict__ A0, int
 // (f64 layout, cdna_hip_programming.md section 3).  MA / MB mask a triangular operand that is
 // stored packed with its sibling triangle: 1 = unit lower (above diagonal 0, diagonal 1),
 // 2 = upper (below diagonal 0).
-typedef double d4 __attribute__((ext_vector_type(4)));
 template <int MODE, int MA, int MB>
 __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_t ldc, int64_t strideC,
                                                    const double* __restrict__ A, int64_t lda, int64_t strideA,
@@ -898,7 +1108,7 @@ __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_
         const int gm = tm + wm + p * 16 + (lane >> 4) + 4 * r;
         const int gn = tn + wn + q * 16 + (lane & 15);
         if (gm < M && gn < N) {
-          if (MODE == 1) C[gm + ldc * gn] -= acc[p][q][r];
+          if (MODE == 1) C[gm + ldc * gn] -= acc[p][q][r];   // (requesting the C tile before the K loop changed nothing: measured)
           else if (MODE == 2) C[gm + ldc * gn] = -acc[p][q][r];
           else C[gm + ldc * gn] = acc[p][q][r];
         }
@@ -918,11 +1128,9 @@ __global__ void k_big_root_update(PlanD P, BatchD B, FrontD F) {
   const double* A = B.scratch + (int64_t)slot * P.scratch_size + F.f_off;
   double* S = B.sblock + (int64_t)slot * P.nS * P.nS;
   const int32_t* rel = P.rel + F.rel_off;
-  const int64_t tot = (int64_t)rs * rs;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
-    const int a = (int)(t % rs), bb = (int)(t / rs);
-    S[rel[ri + a] + (int64_t)P.nS * rel[ri + bb]] += A[(w + ri + a) + (int64_t)m * (w + ri + bb)];   // (targets are unique within a root)
-  }
+  if (rs <= 0) return;
+  for (Idx2 q(blockIdx.x * blockDim.x + threadIdx.x, rs, gridDim.x * blockDim.x); q.j < rs; q.next())
+    S[rel[ri + q.i] + (int64_t)P.nS * rel[ri + q.j]] += A[(w + ri + q.i) + (int64_t)m * (w + ri + q.j)];   // (targets are unique within a root)
 }
 void root_update(const PlanD& P, const BatchD& B, const FrontD& F, int32_t nbc) {
   if (nbc <= 0 || F.rs <= 0) return;
@@ -941,6 +1149,7 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
   if (nbc <= 0) return;
   if (!ctx().big_attr_set) {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_big_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((PIECE * PIECE + 2 * PIECE) * sizeof(double))));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_big_pivot_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((PIECE * PIECE + PIVB_LT * PB) * sizeof(double))));
     ctx().big_attr_set = true;
   }
   if (nbc > 65535) throw Error(-3, "too many batch members for the big-front path");
@@ -967,7 +1176,14 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     const int off = k * PIECE, wk = std::min(PIECE, w - off), rk = m - off - wk;
     double* Ak = A0 + off * (ld + 1);
     double* tk = B.tmp + (int64_t)k * 2 * PIECE * PIECE;
-    hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(PIVOT_T), (size_t)(wk * wk + 2 * wk) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
+    static const bool scalar_pivot = std::getenv("HYMLS_MI_PIVOT_BLOCKED") && std::atoi(std::getenv("HYMLS_MI_PIVOT_BLOCKED")) == 0;   // (A/B switch)
+    const int Wk = (wk + PB - 1) / PB * PB;
+    // (measured, tools/pivot_check.hip: the blocked kernel wins unless the identity padding to a multiple of 32 is large)
+    if (scalar_pivot || !(wk > 96 || (wk > 16 && Wk - wk < 24))) {
+      hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(PIVOT_T), (size_t)(wk * wk + 2 * wk) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
+    } else {
+      hipLaunchKernelGGL(k_big_pivot_blk, dim3(nbc), dim3(PIVB_T), (size_t)(Wk * Wk + PIVB_LT * PB) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
+    }
     launch_check();
     if (rk > 0) {
       hipLaunchKernelGGL(k_big_trmm_u, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);

@@ -321,32 +321,34 @@ void MergedSolve::solve(const dev::PlanD* d_plans, double* x, double* y, int64_t
 }
 
 // ------------------------------------------------------------------ DirectSolver
-DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids, int64_t ngid,
-                           const Params& cp, const ivec* clu_ptr, const ivec* clu, const ivec* clu_coord, bool border_pending) {
-  // CoarseSolver::Compute (reference src/HYMLS_CoarseSolver.cpp:131-152)
+// CoarseSolver::Compute (reference src/HYMLS_CoarseSolver.cpp:131-152), value part: dropping, Dirichlet rows of the fixed
+// gids, the pressure node that joins a pending border.  fix_rows: local rows of the fixed gids.
+Csr DirectSolver::prepare(const Csr& A0, const ivec& gids, const ivec& fix_gids, const Params& cp, bool border_pending, ivec& fix_rows) {
   Csr A = drop_by_value(A0, SMALL_ENTRY, 2);
-  n_ = A.n;
+  const int32_t n = A.n;
+  fix_rows.clear();
   for (int32_t g : fix_gids) {
     int lid = -1;
-    for (int i = 0; i < n_; i++) if (gids[i] == g) { lid = i; break; }
+    for (int i = 0; i < n; i++) if (gids[i] == g) { lid = i; break; }
     HYMLS_CHECK(lid >= 0, -2, "fix GID " + std::to_string(g) + " not in matrix row map");
     // PutDirichlet (reference src/HYMLS_MatrixUtils.cpp:1229-1309)
-    for (int i = 0; i < n_; i++)
+    for (int i = 0; i < n; i++)
       for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++) {
         if (i == lid) A.val[e] = (A.col[e] == lid) ? 1.0 : 0.0;
         else if (A.col[e] == lid) A.val[e] = 0.0;
       }
-    fix_lids_.push_back(lid);
+    fix_rows.push_back(lid);
   }
-  if (border_pending && fix_gids.empty() && n_ > 0) {
+  tail_z_ = -1;
+  if (border_pending && fix_gids.empty() && n > 0) {
     // the last pressure node (if the problem has pressures) joins the border: its row and column are kept aside and
     // replaced by a Dirichlet row in the matrix that is factored
     int z = -1;
-    for (int i = n_ - 1; i >= 0 && z < 0; i--) if (cp.vtype[gids[i] % cp.dof] == VT_P) z = i;
+    for (int i = n - 1; i >= 0 && z < 0; i--) if (cp.vtype[gids[i] % cp.dof] == VT_P) z = i;
     if (z >= 0) {
       tail_z_ = z;
-      tail_col_.assign(n_, 0.0); tail_row_.assign(n_, 0.0);
-      for (int i = 0; i < n_; i++)
+      tail_col_.assign(n, 0.0); tail_row_.assign(n, 0.0);
+      for (int i = 0; i < n; i++)
         for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++) {
           const int c = A.col[e];
           if (i == z && c == z) { tail_d_ = A.val[e]; A.val[e] = 1.0; }
@@ -355,14 +357,40 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
         }
     }
   }
+  return A;
+}
+
+static std::vector<char> zero_diagonal(const Csr& A) {
+  std::vector<char> zd((size_t)A.n, 1);
+  for (int i = 0; i < A.n; i++)
+    for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++)
+      if (A.col[e] == i && A.val[e] != 0.0) zd[i] = 0;
+  return zd;
+}
+
+void DirectSolver::numeric(const dvec& val) {
+  if (!d_val_) d_val_ = dev::upload(val);
+  else dev::h2d(d_val_, val.data(), val.size() * sizeof(double));
+  lu_->factor_chunk(d_val_, 0, 1);
+  double g = 0.0;
+  const int32_t f = lu_->check_flag(&g);
+  if (std::getenv("HYMLS_MI_VERBOSE")) std::fprintf(stderr, "[hymls_mi] coarse solver: largest element growth of a pivot block %.3g\n", g);
+  HYMLS_CHECK((f & 1) == 0, -4, "coarse factorisation hit a zero or non-finite pivot");
+  HYMLS_CHECK((f & 2) == 0, -4, "coarse factorisation without pivoting is unstable for this matrix: element growth " + std::to_string(g) + " > 1e8");
+}
+
+DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids, int64_t ngid,
+                           const Params& cp, const ivec* clu_ptr, const ivec* clu, const ivec* clu_coord, bool border_pending) {
+  ivec fix_rows;
+  Csr A = prepare(A0, gids, fix_gids, cp, border_pending, fix_rows);
+  n_ = A.n;
+  border_pending_ = border_pending;
   if (n_ == 0) return;
   LocalPattern lp;
   lp.nI = n_; lp.nS = 0;
   lp.rowptr = A.rowptr; lp.col = A.col;
-  lp.zero_diag.assign(n_, 1);
-  for (int i = 0; i < n_; i++)
-    for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++)
-      if (A.col[e] == i && A.val[e] != 0.0) lp.zero_diag[i] = 0;
+  pat_zero_diag_ = zero_diagonal(A);
+  lp.zero_diag.assign(pat_zero_diag_.begin(), pat_zero_diag_.end());
   lp.coord.resize(3 * (size_t)n_);
   for (int i = 0; i < n_; i++) gid_coord(cp, gids[i], &lp.coord[3 * (size_t)i]);
   (void)ngid;
@@ -377,15 +405,7 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   lu_->h_src.resize(A.col.size());
   std::iota(lu_->h_src.begin(), lu_->h_src.end(), 0);
   lu_->upload(SCRATCH_BUDGET, false);
-  d_val_ = dev::upload(A.val);
-  lu_->factor_chunk(d_val_, 0, 1);
-  {
-    double g = 0.0;
-    const int32_t f = lu_->check_flag(&g);
-    if (std::getenv("HYMLS_MI_VERBOSE")) std::fprintf(stderr, "[hymls_mi] coarse solver: largest element growth of a pivot block %.3g\n", g);
-    HYMLS_CHECK((f & 1) == 0, -4, "coarse factorisation hit a zero or non-finite pivot");
-    HYMLS_CHECK((f & 2) == 0, -4, "coarse factorisation without pivoting is unstable for this matrix: element growth " + std::to_string(g) + " > 1e8");
-  }
+  numeric(A.val);
   d_perm_ = dev::upload(lu_->plan.perm);
   // the tree levels of one large system are launch-latency bound with one launch chain per level (assemble, panels,
   // finalize, small fronts: about 100 launches per solve at 216 k unknowns); the merged task kernels need one launch
@@ -394,11 +414,24 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
     merged_.build({{0, lu_.get()}});
     d_plan_ = dev::upload(std::vector<dev::PlanD>{lu_->dplan});
   }
-  ivec fixpos;
-  for (int lid : fix_lids_)
-    if (lid > 0) fixpos.push_back(lu_->plan.iperm[lid]);  // CoarseSolver.cpp:288-289: lid 0 is not zeroed
-  fix_lids_ = fixpos;
+  for (int lid : fix_rows)
+    if (lid > 0) fix_lids_.push_back(lu_->plan.iperm[lid]);  // CoarseSolver.cpp:288-289: lid 0 is not zeroed
   d_fix_ = dev::upload(fix_lids_);
+  pat_rowptr_ = std::move(A.rowptr); pat_col_ = std::move(A.col); pat_gids_ = gids; pat_fix_ = fix_gids;
+}
+
+// Compute with an unchanged pattern (a Newton step: same rows, same kept entries, same zero diagonals): the ordering, the
+// symbolic factorisation and every index table on the device stay, only the numeric factorisation is redone.  (The
+// reference's CoarseSolver keeps its Amesos solver across Compute calls in the same way, CoarseSolver.cpp:131-152.)
+bool DirectSolver::refactor(const Csr& A0, const ivec& gids, const ivec& fix_gids, const Params& cp, bool border_pending) {
+  if (n_ == 0 || !lu_ || border_pending != border_pending_ || gids != pat_gids_ || fix_gids != pat_fix_) return false;
+  const int32_t tail_before = tail_z_;
+  ivec fix_rows;
+  Csr A = prepare(A0, gids, fix_gids, cp, border_pending, fix_rows);
+  if (A.n != n_ || tail_z_ != tail_before || A.rowptr != pat_rowptr_ || A.col != pat_col_ || zero_diagonal(A) != pat_zero_diag_) return false;
+  if (std::getenv("HYMLS_MI_VERBOSE")) std::fprintf(stderr, "[hymls_mi] coarse solver: pattern unchanged, numeric refactorisation with the existing plan\n");
+  numeric(A.val);
+  return true;
 }
 
 DirectSolver::~DirectSolver() {
@@ -1605,11 +1638,14 @@ void LevelSolver::compute() {
     // Preconditioner.cpp:485-500: S assembled, DropByValue (RelZeroDiag), CoarseSolver
     const Csr& G = assemble_reduced(next_gids, nullptr);
     Csr S = drop_by_value(G, SMALL_ENTRY, 1);
-    next_.reset();
-    next_level_ = nullptr;
-    next_is_direct_ = true;
-    next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &glob_clu_ptr_, &glob_clu_, &glob_sd_center_, bm_ > 0));
-    build_handoff(next_gids);
+    DirectSolver* ds = next_is_direct_ && !next_level_ ? dynamic_cast<DirectSolver*>(next_.get()) : nullptr;
+    if (!(ds && ds->refactor(S, next_gids, p_.fix_gid, p_, bm_ > 0))) {
+      next_.reset();
+      next_level_ = nullptr;
+      next_is_direct_ = true;
+      next_.reset(new DirectSolver(S, next_gids, p_.fix_gid, ngid_, p_, &glob_clu_ptr_, &glob_clu_, &glob_sd_center_, bm_ > 0));
+      build_handoff(next_gids);
+    }
     set_next_border();
     return;
   }
@@ -1687,10 +1723,14 @@ void LevelSolver::compute() {
     next_level_->compute();
     lap("next level compute");
   } else {
-    next_level_ = nullptr;
-    next_is_direct_ = true;
-    next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &glob_clu_ptr_, &glob_clu_, &glob_sd_center_, bm_ > 0));
-    build_handoff(next_gids);
+    DirectSolver* ds = next_is_direct_ && !next_level_ ? dynamic_cast<DirectSolver*>(next_.get()) : nullptr;
+    if (!(ds && ds->refactor(R, next_gids, p_.fix_gid, p_, bm_ > 0))) {
+      next_.reset();            // (the old factor goes before the new one is built)
+      next_level_ = nullptr;
+      next_is_direct_ = true;
+      next_.reset(new DirectSolver(R, next_gids, p_.fix_gid, ngid_, p_, &glob_clu_ptr_, &glob_clu_, &glob_sd_center_, bm_ > 0));
+      build_handoff(next_gids);
+    }
     set_next_border();
     lap("coarse solver");
   }

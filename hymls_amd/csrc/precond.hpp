@@ -99,6 +99,9 @@ class DirectSolver : public Operator {
                const ivec* clu_ptr = nullptr, const ivec* clu = nullptr, const ivec* clu_coord = nullptr,
                bool border_pending = false);
   ~DirectSolver() override;
+  // numeric factorisation only, if A0 (same gids, fixes, border state) still has the pattern this solver was analysed for;
+  // false (nothing changed) otherwise: the caller builds a new solver then
+  bool refactor(const Csr& A0, const ivec& gids, const ivec& fix_gids, const Params& coord_params, bool border_pending);
   void apply_inverse(const double* b, double* x) override;
   void apply_inverse_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv) override;
   void set_border(int m, const double* dV, const double* dW, const double* C) override;
@@ -109,6 +112,11 @@ class DirectSolver : public Operator {
  private:
   void solve(const double* b, double* x, bool zero_fixed);
   void solve_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv, bool zero_fixed);
+  Csr prepare(const Csr& A0, const ivec& gids, const ivec& fix_gids, const Params& cp, bool border_pending, ivec& fix_rows);
+  void numeric(const dvec& val);
+  ivec pat_rowptr_, pat_col_, pat_gids_, pat_fix_;   // what the plan was built for
+  std::vector<char> pat_zero_diag_;
+  bool border_pending_ = false;
   int32_t n_ = 0;
   int nv_alloc_ = 0;
   // border: x = A^{-1} b - Z y, y = (C - W' Z)^{-1} (T - W' A^{-1} b), Z = A^{-1} V

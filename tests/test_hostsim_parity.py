@@ -304,3 +304,28 @@ def test_separator_block_inversion_hostsim(hostsim_lib):
     for q in range(3):
         assert np.abs(X[q] @ B[q] - np.eye(37)).max() <= 1e-12 * np.linalg.cond(B[q])
     assert P.InvertBlocks(np.zeros((0, 5, 5))).shape == (0, 5, 5)
+
+
+@pytest.mark.parametrize("eq,n,sx,levels,cx", [("Laplace", 16, 4, 1, -1), ("Stokes-C", 16, 8, 1, -1), ("Laplace", 16, 4, 2, 2)])
+def test_recompute_keeps_the_coarse_plan_hostsim(hostsim_lib, eq, n, sx, levels, cx):
+    """SetMatrix + Compute with the same pattern: the coarse direct solver keeps its ordering and symbolic factorisation and
+    only refactors (CoarseSolver::Compute keeps its Amesos solver in the reference, src/HYMLS_CoarseSolver.cpp:131-152);
+    the result must be what a fresh preconditioner for the new matrix gives, also after going back to the first matrix."""
+    A, tv = problem(eq, n)
+    P = product_prec(A, tv, xml_params(eq, n, sx, levels, cx, "Skew Cartesian" if eq == "Stokes-C" else "Cartesian"), hostsim_lib)
+    b = np.random.default_rng(11).uniform(-1, 1, A.shape[0])
+    rng = np.random.default_rng(12)
+    A2 = A.copy()
+    A2.data = A2.data * (1.0 + 0.05 * rng.uniform(-1, 1, A2.data.size))       # same pattern, other values
+    if eq == "Stokes-C":
+        A2 = A.copy(); A2.data = A2.data * 1.5
+    P.SetMatrix(A2)
+    P.Compute()
+    F = product_prec(A2, tv, xml_params(eq, n, sx, levels, cx, "Skew Cartesian" if eq == "Stokes-C" else "Cartesian"), hostsim_lib)
+    assert rel_diff(P.ApplyInverse(b), F.ApplyInverse(b)) < 1e-12
+    # back to the first matrix: again a refactorisation
+    P.SetMatrix(A)
+    P.Compute()
+    F = product_prec(A, tv, xml_params(eq, n, sx, levels, cx, "Skew Cartesian" if eq == "Stokes-C" else "Cartesian"), hostsim_lib)
+    assert rel_diff(P.ApplyInverse(b), F.ApplyInverse(b)) < 1e-12
+    assert P.NumInitialize() == 1 and P.NumCompute() == 3

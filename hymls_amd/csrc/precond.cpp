@@ -321,6 +321,7 @@ void MergedSolve::solve(const dev::PlanD* d_plans, double* x, double* y, int64_t
 }
 
 // ------------------------------------------------------------------ DirectSolver
+static double wall();
 // CoarseSolver::Compute (reference src/HYMLS_CoarseSolver.cpp:131-152), value part: dropping, Dirichlet rows of the fixed
 // gids, the pressure node that joins a pending border.  fix_rows: local rows of the fixed gids.
 Csr DirectSolver::prepare(const Csr& A0, const ivec& gids, const ivec& fix_gids, const Params& cp, bool border_pending, ivec& fix_rows) {
@@ -396,15 +397,21 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   (void)ngid;
   if (clu_ptr && !clu_ptr->empty() && !std::getenv("HYMLS_MI_NO_CLUSTER_ND")) { lp.clu_ptr = *clu_ptr; lp.clu = *clu; lp.clu_coord = *clu_coord; }
   lu_.reset(new BatchedLU());
+  const double t_an = wall();
   lu_->plan = analyse_class(lp, LEAF_SIZE_COARSE, MAX_WIDTH_COARSE, 65536);
-  if (std::getenv("HYMLS_MI_VERBOSE")) print_plan_stats(lu_->plan, "coarse solver", 1);
+  if (std::getenv("HYMLS_MI_VERBOSE")) {
+    std::fprintf(stderr, "[hymls_mi] coarse solver: ordering + symbolic factorisation + plan %.2f s (host)\n", wall() - t_an);
+    print_plan_stats(lu_->plan, "coarse solver", 1);
+  }
   lu_->members = {0};
   lu_->h_xoff = {0};
   lu_->contrib_nv = dev::NV_MAX;
   // entry e of the extended CSR is entry e of A
   lu_->h_src.resize(A.col.size());
   std::iota(lu_->h_src.begin(), lu_->h_src.end(), 0);
+  const double t_up = wall();
   lu_->upload(SCRATCH_BUDGET, false);
+  if (std::getenv("HYMLS_MI_VERBOSE")) std::fprintf(stderr, "[hymls_mi] coarse solver: plan upload + allocations %.2f s\n", wall() - t_up);
   numeric(A.val);
   d_perm_ = dev::upload(lu_->plan.perm);
   // the tree levels of one large system are launch-latency bound with one launch chain per level (assemble, panels,

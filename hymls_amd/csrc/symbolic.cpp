@@ -1,6 +1,9 @@
 // symbolic.cpp -- see symbolic.hpp
 #include "symbolic.hpp"
 #include <iterator>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace hymls {
 
@@ -217,6 +220,15 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   ClassPlan P;
   const int nI = lp.nI, nS = lp.nS, n = nI + nS;
   P.nI = nI; P.nS = nS;
+  static const bool prof_an = std::getenv("HYMLS_MI_ANALYSE_PROF") != nullptr;   // development aid: seconds per section on stderr
+  auto t_an = std::chrono::steady_clock::now();
+  auto lap_an = [&](const char* what) {
+    if (!prof_an || n < 10000) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[hymls_mi] analyse_class section before mark %s: %.3f s\n", what, std::chrono::duration<double>(t - t_an).count());
+    t_an = t;
+  };
+  lap_an("0");
   // --- symmetric adjacency of the extended pattern
   std::vector<ivec> adj(n);
   for (int i = 0; i < n; i++)
@@ -225,6 +237,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
       if (j != i) { adj[i].push_back(j); adj[j].push_back(i); }
     }
   for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  lap_an("1");
   // --- V-graph (A + B B^T) on interior V-nodes
   std::vector<ivec> vadj(nI);
   std::vector<ivec> pv(nI);  // for P-nodes: interior V neighbours; for V-nodes: interior P neighbours
@@ -238,6 +251,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
     if (lp.zero_diag[p])
       for (int a : pv[p]) for (int b : pv[p]) if (a != b) vadj[a].push_back(b);
   for (auto& a : vadj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  lap_an("2");
   // --- nested dissection of the V-nodes
   NdCtx c;
   c.vadj = &vadj; c.coord = &lp.coord; c.leaf = std::max(leaf_size, 1);
@@ -267,6 +281,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   } else {
     nd_recurse(c, vnodes);
   }
+  lap_an("3");
   // --- attach every P-node behind a V-node that grounds it (union-find over pressures;
   //     the id nI stands for "boundary / separator / no second pressure")
   ivec uf(nI + 1);
@@ -302,6 +317,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   HYMLS_CHECK((int)P.perm.size() == nI, -3, "ordering lost nodes");
   P.iperm.assign(nI, -1);
   for (int i = 0; i < nI; i++) P.iperm[P.perm[i]] = i;
+  lap_an("4");
   // --- sparse-equivalent size of the factors: nnz(L + U) of a scalar (column by column) LU of the interior block in this
   //     elimination order, without supernode padding, dense leaves or explicit triangular inverses -- what a sparse
   //     solver such as the reference's KLU would stream per solve (the smaller of this and the stored
@@ -333,6 +349,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   ivec sn_of(nI);
   for (int s = 0; s < nf; s++) for (int t = sn[s].first; t < sn[s].second; t++) sn_of[t] = s;
   auto pos_of = [&](int node) { return node < nI ? P.iperm[node] : node; };  // separators keep nI + id
+  lap_an("5");
   // --- symbolic factorisation on the given supernode partition
   P.fronts.resize(nf);
   std::vector<ivec> kids(nf);
@@ -357,6 +374,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
     F.parent = (F.ri > 0) ? sn_of[R[0]] : -1;
     if (F.parent >= 0) kids[F.parent].push_back(s);
   }
+  lap_an("6");
   // --- levels
   int maxlev = 0;
   for (int s = 0; s < nf; s++) {
@@ -369,6 +387,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   P.big_levels.assign(nf ? maxlev + 1 : 0, ivec());
   P.flevels.assign(nf ? maxlev + 1 : 0, ivec());
   P.fwide_levels.assign(nf ? maxlev + 1 : 0, ivec());
+  lap_an("7");
   // --- index lists, offsets
   int64_t foff = 0, fac = 0;
   int32_t coff = 0, aoff = 0;
@@ -438,6 +457,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
     }
   }
   P.scratch_size = foff; P.factor_size = fac; P.contrib_size = coff;
+  lap_an("8");
   // --- relative maps (update rows -> position in the parent's index list / separator id)
   ivec where(n, -1);
   for (int s = 0; s < nf; s++) P.fronts[s].rel_off = -1;
@@ -464,6 +484,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
     if (F.parent >= 0) continue;
     for (int t = 0; t < F.rs; t++) P.rel[F.rel_off + t] = P.fidx[F.idx_off + F.w + t] - nI;
   }
+  lap_an("9");
   // --- assembly pull lists: for every row of every front's solve vector [pivot | update rows]
   //     the contribution-vector entries of its children that land there (fixed order)
   P.asm_rows = aoff;
@@ -482,6 +503,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
       P.asm_ptr[i + 1] = (int32_t)P.asm_src.size();
     }
   }
+  lap_an("10");
   // --- work items of the level-synchronous fused solve
   {
     const int nl = (int)P.levels.size();
@@ -502,51 +524,65 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
       P.bw_ptr.push_back((int32_t)P.bw_items.size());
     }
   }
+  lap_an("11");
   // --- matrix entries -> fronts
-  struct Ent { int32_t front, id, pos; double w; };
-  std::vector<Ent> ents;
-  ents.reserve(lp.col.size());
+  // counting sort of the entries by front (ascending entry index within a front), then positions front by front; one
+  // large system (the coarse solver: 1e7 entries and more) spreads both passes over the host threads
   {
-    // per-front position lookup: process entries grouped by front via counting sort
-    std::vector<ivec> byfront(nf + 1);
-    for (int i = 0; i < n; i++)
+    const int64_t nnz = (int64_t)lp.col.size();
+    const bool par = n >= 20000;
+    ivec rowof((size_t)nnz), ent_front((size_t)nnz);
+    auto classify = [&](int64_t i) {
       for (int e = lp.rowptr[i]; e < lp.rowptr[i + 1]; e++) {
-        const int pi = pos_of(i), pj = pos_of(lp.col[e]);
-        const int pm = std::min(pi, pj);
-        byfront[pm < nI ? sn_of[pm] : nf].push_back(e);
+        rowof[e] = (int)i;
+        const int pm = std::min(pos_of((int)i), pos_of(lp.col[e]));
+        ent_front[e] = pm < nI ? sn_of[pm] : nf;
       }
-    ivec rowof(lp.col.size());
-    for (int i = 0; i < n; i++) for (int e = lp.rowptr[i]; e < lp.rowptr[i + 1]; e++) rowof[e] = i;
-    for (int s = 0; s <= nf; s++) {
-      if (s < nf) {
-        const Front& F = P.fronts[s];
-        for (int t = 0; t < F.m(); t++) where[P.fidx[F.idx_off + t]] = t;
-        for (int e : byfront[s]) {
-          const int a = where[pos_of(rowof[e])], b = where[pos_of(lp.col[e])];
-          HYMLS_CHECK(a >= 0 && b >= 0, -3, "symbolic: matrix entry outside its front");
-          ents.push_back({s, e, a + F.m() * b, lp.weight.empty() ? 1.0 : lp.weight[e]});
+    };
+    if (par) parallel_for(n, classify, 4096); else for (int i = 0; i < n; i++) classify(i);
+    std::vector<int64_t> fptr((size_t)nf + 2, 0);
+    for (int64_t e = 0; e < nnz; e++) fptr[ent_front[e] + 1]++;
+    for (int s2 = 0; s2 <= nf; s2++) fptr[s2 + 1] += fptr[s2];
+    P.ent_id.resize((size_t)nnz); P.ent_pos.resize((size_t)nnz); P.ent_w.resize((size_t)nnz);
+    {
+      std::vector<int64_t> cur(fptr.begin(), fptr.end() - 1);
+      for (int64_t e = 0; e < nnz; e++) P.ent_id[cur[ent_front[e]]++] = (int32_t)e;
+    }
+    auto place = [&](int64_t s2) {
+      const int sf = (int)s2;
+      if (sf < nf) {
+        if (fptr[sf] == fptr[sf + 1]) return;
+        static thread_local ivec wh;                 // node position -> row of the front, -1 outside (restored after use)
+        if ((int)wh.size() < n) wh.resize(n, -1);
+        const Front& F = P.fronts[sf];
+        for (int t = 0; t < F.m(); t++) wh[P.fidx[F.idx_off + t]] = t;
+        bool ok = true;
+        for (int64_t k = fptr[sf]; k < fptr[sf + 1]; k++) {
+          const int e = P.ent_id[k];
+          const int a = wh[pos_of(rowof[e])], b = wh[pos_of(lp.col[e])];
+          ok = ok && a >= 0 && b >= 0;
+          P.ent_pos[k] = a + F.m() * b;
+          P.ent_w[k] = lp.weight.empty() ? 1.0 : lp.weight[e];
         }
-        for (int t = 0; t < F.m(); t++) where[P.fidx[F.idx_off + t]] = -1;
+        for (int t = 0; t < F.m(); t++) wh[P.fidx[F.idx_off + t]] = -1;
+        HYMLS_CHECK(ok, -3, "symbolic: matrix entry outside its front");
       } else {
-        for (int e : byfront[s])
-          ents.push_back({s, e, (rowof[e] - nI) + nS * (lp.col[e] - nI), lp.weight.empty() ? 1.0 : lp.weight[e]});
+        for (int64_t k = fptr[nf]; k < fptr[nf + 1]; k++) {
+          const int e = P.ent_id[k];
+          P.ent_pos[k] = (rowof[e] - nI) + nS * (lp.col[e] - nI);
+          P.ent_w[k] = lp.weight.empty() ? 1.0 : lp.weight[e];
+        }
       }
+    };
+    if (par) parallel_for(nf + 1, place, 8); else for (int s2 = 0; s2 <= nf; s2++) place(s2);
+    for (int s2 = 0; s2 < nf; s2++) {
+      const bool any = fptr[s2] < fptr[s2 + 1];
+      P.fronts[s2].ent_begin = any ? (int32_t)fptr[s2] : 0;
+      P.fronts[s2].ent_end = any ? (int32_t)fptr[s2 + 1] : 0;
     }
+    P.s_ent_begin = (int32_t)fptr[nf];
   }
-  P.ent_id.resize(ents.size()); P.ent_pos.resize(ents.size()); P.ent_w.resize(ents.size());
-  for (int s = 0; s < nf; s++) P.fronts[s].ent_begin = P.fronts[s].ent_end = 0;
-  {
-    int cur = -1;
-    for (size_t k = 0; k < ents.size(); k++) {
-      P.ent_id[k] = ents[k].id; P.ent_pos[k] = ents[k].pos; P.ent_w[k] = ents[k].w;
-      if (ents[k].front != cur) {
-        cur = ents[k].front;
-        if (cur < nf) P.fronts[cur].ent_begin = (int32_t)k; else P.s_ent_begin = (int32_t)k;
-      }
-      if (cur < nf) P.fronts[cur].ent_end = (int32_t)k + 1;
-    }
-    if (cur < nf || ents.empty()) P.s_ent_begin = (int32_t)ents.size();
-  }
+  lap_an("end");
   return P;
 }
 

@@ -3099,7 +3099,9 @@ bool dense_invert_blocked_order(int32_t nb) { return nb >= gj_blocked_min() && n
 void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag) {
   if (nb <= 0 || nblk <= 0) return;
   if (dense_invert_blocked_order(nb)) {
-    for (int32_t b0 = 0; b0 < nblk; b0 += 65535) dense_invert_blocked(nb, std::min(65535, nblk - b0), blocks + (int64_t)b0 * nb * nb, flag);
+    // (chunks: the panel workspace W | R of a call stays below 1 GiB, the grid below 65536 blocks)
+    const int32_t per = (int32_t)std::max<int64_t>(1, std::min<int64_t>(65535, ((int64_t)1 << 30) / ((int64_t)2 * nb * GJB * sizeof(double))));
+    for (int32_t b0 = 0; b0 < nblk; b0 += per) dense_invert_blocked(nb, std::min(per, nblk - b0), blocks + (int64_t)b0 * nb * nb, flag);
     return;
   }
   if (nb <= GJ_LDS_NB)

@@ -2041,7 +2041,8 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
 // 335-344): the factor panels, the dominant bytes of a solve, are streamed ONCE for a group of NV columns -- every panel
 // entry loaded is used for NV multiply-adds.  Vectors are column-major with a leading dimension; the kernels are the
 // single-vector ones with the per-row state (accumulators, LDS vectors) replicated NV times.  A launcher picks the
-// widest group (4, 2, 1) whose LDS fits and walks over the columns.
+// widest group (4, 2, 1) whose LDS fits and walks over the columns.  (Measured and not kept: 16 / 8 panel entries requested per
+// thread ahead of their use instead of 4 -- the 4-column kernel got 10 % slower; it is not short of bytes in flight.)
 constexpr size_t LDS_LIMIT_BYTES = 160 * 1024;
 // widest column group of a launcher (development switch: HYMLS_MI_MV_GROUP_<FUSED|LVL|BLK> = 1, 2 or 4)
 static int mv_group_cap(const char* which) {

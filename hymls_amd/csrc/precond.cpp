@@ -1600,16 +1600,24 @@ void LevelSolver::compute() {
   dev::gather((int64_t)a21_col_.size(), d_a21_src_, d_kval_, d_a21_val_);
   // ---- interior factorisations + separator blocks, class by class, chunk by chunk.  The coarser levels have many
   // classes with one or two large subdomains each: their launch chains are independent and run on side streams
-  const bool side = level_ >= 1 && cls_.size() > 1 && !std::getenv("HYMLS_MI_NO_SIDE_STREAMS");
+  // The finest level has a few classes with thousands of members: there the CHUNKS of a class alternate between two side
+  // streams, so that the narrow launches at the top of one chunk's elimination tree overlap the leaf launches of the next
+  // (HYMLS_MI_CHUNK_STREAMS = 0 switches that off, 1..NSIDE sets the number of streams).
+  const bool no_side = std::getenv("HYMLS_MI_NO_SIDE_STREAMS") != nullptr;
+  const bool side = level_ >= 1 && cls_.size() > 1 && !no_side;
+  static const int chunk_streams_env = std::getenv("HYMLS_MI_CHUNK_STREAMS") ? std::atoi(std::getenv("HYMLS_MI_CHUNK_STREAMS")) : 2;
+  const int chunk_streams = level_ == 0 && !no_side ? std::max(0, std::min(chunk_streams_env, dev::NSIDE)) : 0;
   struct MainStreamGuard { ~MainStreamGuard() { try { dev::use_stream(0); } catch (...) {} } } back_to_main;   // also when a launch throws
-  if (side) dev::fork_streams();
+  for (auto& cp : cls_) dev::zero(cp->lu.batch.flag, 4 * sizeof(int32_t));   // (on the main stream, before any side stream starts)
+  if (side || chunk_streams) dev::fork_streams();
+  int64_t chunk_id = 0;
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
     if (side) dev::use_stream(1 + (int)(c % dev::NSIDE));
-    dev::zero(C.lu.batch.flag, 4 * sizeof(int32_t));
     const int nb = (int)C.lu.members.size();
     for (int b0 = 0; b0 < nb; b0 += C.lu.chunk) {
       const int nbc = std::min(C.lu.chunk, nb - b0);
+      if (chunk_streams) dev::use_stream(1 + (int)(chunk_id++ % chunk_streams));
       C.lu.factor_chunk(d_kval_, b0, nbc);
       C.lu.repack_chunk(b0, nbc);
       if (C.pat.nS == 0) continue;
@@ -1624,7 +1632,7 @@ void LevelSolver::compute() {
       }
     }
   }
-  if (side) dev::join_streams();
+  if (side || chunk_streams) dev::join_streams();
   int32_t bad = 0, grown = 0;
   double growth = 0.0;
   for (auto& cp : cls_) { double g = 0.0; const int32_t f = cp->lu.check_flag(&g); bad |= (f & 1); grown |= (f & 2) >> 1; growth = std::max(growth, g); }

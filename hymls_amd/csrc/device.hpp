@@ -34,7 +34,11 @@ void* shared_scratch(size_t bytes);
 // launch after the other): fork_streams() makes the side streams wait for the main one, use_stream(k) directs every
 // following launch / copy / scratch request to stream k (0 = main, 1..NSIDE), join_streams() makes the main stream wait
 // for all of them and switches back to it
-constexpr int NSIDE = 4;
+constexpr int NSIDE = 8;   // streams that exist; side_streams() of them are used (HYMLS_MI_SIDE_STREAMS, default 4)
+inline int side_streams() {
+  static const int n = std::getenv("HYMLS_MI_SIDE_STREAMS") ? std::max(1, std::min(NSIDE, std::atoi(std::getenv("HYMLS_MI_SIDE_STREAMS")))) : 4;
+  return n;
+}
 void fork_streams();
 void use_stream(int k);
 void join_streams();

@@ -191,14 +191,31 @@ void BatchedLU::bind_scratch() {
   batch.tmp = tmp_need_ ? a + scratch_need_ + sblock_need_ : nullptr;
 }
 
-void BatchedLU::factor_chunk(const double* kval, int32_t b0, int32_t nbc) {
+void BatchedLU::factor_chunk(const double* kval, int32_t b0, int32_t nbc, bool spread_wide) {
   bind_scratch();
   if (batch.sblock) dev::sblock_init(dplan, batch, b0, nbc, kval);
+  // spread_wide (one large system factored from the main stream: the last-level solver): the wide fronts of a tree level
+  // are independent launch chains of small grids -- they go to the side streams, each with pivot-piece workspace of its own
+  const bool spread = spread_wide && dev::side_streams() > 1 && !std::getenv("HYMLS_MI_NO_SIDE_STREAMS");
+  struct MainStreamGuard { bool on; ~MainStreamGuard() { if (on) { try { dev::use_stream(0); } catch (...) {} } } } back_to_main{spread};
   for (size_t l = 0; l < plan.flevels.size(); l++) {
     int32_t mw = 1;
     for (int s : plan.flevels[l]) mw = std::max(mw, plan.fronts[s].w);
     dev::factor_level(dplan, batch, d_flists[l], (int32_t)plan.flevels[l].size(), b0, nbc, kval, mw);
-    for (int s : plan.fwide_levels[l]) {
+    const auto& wide = plan.fwide_levels[l];
+    if (spread && wide.size() > 1) {
+      dev::fork_streams();
+      for (size_t q = 0; q < wide.size(); q++) {
+        dev::use_stream(1 + (int)(q % dev::side_streams()));
+        dev::BatchD bq = batch;
+        bq.tmp = tmp_need_ ? (double*)dev::shared_scratch((size_t)tmp_need_ * sizeof(double)) : nullptr;
+        auto k = kids_of(wide[q]);
+        dev::factor_big_front(dplan, bq, h_fronts[wide[q]], k.data(), (int32_t)k.size(), b0, nbc, kval);
+      }
+      dev::join_streams();
+      continue;
+    }
+    for (int s : wide) {
       auto k = kids_of(s);
       dev::factor_big_front(dplan, batch, h_fronts[s], k.data(), (int32_t)k.size(), b0, nbc, kval);
     }
@@ -372,7 +389,7 @@ static std::vector<char> zero_diagonal(const Csr& A) {
 void DirectSolver::numeric(const dvec& val) {
   if (!d_val_) d_val_ = dev::upload(val);
   else dev::h2d(d_val_, val.data(), val.size() * sizeof(double));
-  lu_->factor_chunk(d_val_, 0, 1);
+  lu_->factor_chunk(d_val_, 0, 1, true);
   double g = 0.0;
   const int32_t f = lu_->check_flag(&g);
   if (std::getenv("HYMLS_MI_VERBOSE")) std::fprintf(stderr, "[hymls_mi] coarse solver: largest element growth of a pivot block %.3g\n", g);
@@ -1606,14 +1623,17 @@ void LevelSolver::compute() {
   const bool no_side = std::getenv("HYMLS_MI_NO_SIDE_STREAMS") != nullptr;
   const bool side = level_ >= 1 && cls_.size() > 1 && !no_side;
   static const int chunk_streams_env = std::getenv("HYMLS_MI_CHUNK_STREAMS") ? std::atoi(std::getenv("HYMLS_MI_CHUNK_STREAMS")) : 2;
-  const int chunk_streams = level_ == 0 && !no_side ? std::max(0, std::min(chunk_streams_env, dev::NSIDE)) : 0;
+  const int chunk_streams = level_ == 0 && !no_side ? std::max(0, std::min(chunk_streams_env, dev::side_streams())) : 0;
   struct MainStreamGuard { ~MainStreamGuard() { try { dev::use_stream(0); } catch (...) {} } } back_to_main;   // also when a launch throws
   for (auto& cp : cls_) dev::zero(cp->lu.batch.flag, 4 * sizeof(int32_t));   // (on the main stream, before any side stream starts)
   if (side || chunk_streams) dev::fork_streams();
   int64_t chunk_id = 0;
+  // (coarser levels: classes in their order, round robin over the side streams.  Measured and not kept: classes in descending
+  // order of work on the least loaded stream -- 1.36 s instead of 1.13 s for level 2 of the 256^3 run with four streams, the
+  // largest classes then run at the same time; six or eight streams: 1.12 s and 15-27 GiB more memory.)
   for (size_t c = 0; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
-    if (side) dev::use_stream(1 + (int)(c % dev::NSIDE));
+    if (side) dev::use_stream(1 + (int)(c % dev::side_streams()));
     const int nb = (int)C.lu.members.size();
     for (int b0 = 0; b0 < nb; b0 += C.lu.chunk) {
       const int nbc = std::min(C.lu.chunk, nb - b0);
@@ -1690,7 +1710,7 @@ void LevelSolver::compute() {
       int k = 0;
       for (auto& B : blocks_)
         if (dev::dense_invert_blocked_order(B.nb)) {
-          dev::use_stream(1 + (k++ % dev::NSIDE));
+          dev::use_stream(1 + (k++ % dev::side_streams()));
           dev::dense_invert(B.nb, B.nblk, B.d_binv, d_flag_);
         }
       dev::use_stream(0);

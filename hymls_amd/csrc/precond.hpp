@@ -46,7 +46,7 @@ struct BatchedLU {
   ~BatchedLU();
   void upload(int64_t scratch_budget_doubles, bool with_sblock);
   // numeric factorisation of members [b0,b0+nbc) (scratch slots 0..nbc-1)
-  void factor_chunk(const double* kval, int32_t b0, int32_t nbc);
+  void factor_chunk(const double* kval, int32_t b0, int32_t nbc, bool spread_wide = false);
   void repack_chunk(int32_t b0, int32_t nbc);
   void bind_scratch();            // point batch.scratch / sblock / tmp into the shared setup arena
   int64_t scratch_need_ = 0, sblock_need_ = 0, tmp_need_ = 0;   // doubles   // after factor_chunk and after the separator block was read

@@ -230,27 +230,45 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   };
   lap_an("0");
   // --- symmetric adjacency of the extended pattern
+  // (one large system -- the last-level solver -- spreads the row-wise passes over the host threads; the classes of a level are
+  // analysed in parallel already)
+  const bool big = n >= 20000;
+  auto rows_for = [&](int64_t count, auto fn) { if (big) parallel_for(count, fn, 1024); else for (int64_t i = 0; i < count; i++) fn(i); };
+  auto sort_unique = [](ivec& a) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); };
   std::vector<ivec> adj(n);
+  {
+    ivec deg(n, 0);
+    for (int i = 0; i < n; i++)
+      for (int e = lp.rowptr[i]; e < lp.rowptr[i + 1]; e++) {
+        const int j = lp.col[e];
+        if (j != i) { deg[i]++; deg[j]++; }
+      }
+    rows_for(n, [&](int64_t i) { adj[i].reserve(deg[i]); });
+  }
   for (int i = 0; i < n; i++)
     for (int e = lp.rowptr[i]; e < lp.rowptr[i + 1]; e++) {
       const int j = lp.col[e];
       if (j != i) { adj[i].push_back(j); adj[j].push_back(i); }
     }
-  for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  rows_for(n, [&](int64_t i) { sort_unique(adj[i]); });
   lap_an("1");
   // --- V-graph (A + B B^T) on interior V-nodes
   std::vector<ivec> vadj(nI);
   std::vector<ivec> pv(nI);  // for P-nodes: interior V neighbours; for V-nodes: interior P neighbours
-  for (int i = 0; i < nI; i++)
+  rows_for(nI, [&](int64_t i) {
     for (int j : adj[i]) {
       if (j >= nI) continue;
       if (lp.zero_diag[i] != lp.zero_diag[j]) pv[i].push_back(j);
       else if (!lp.zero_diag[i]) vadj[i].push_back(j);
     }
-  for (int p = 0; p < nI; p++)
-    if (lp.zero_diag[p])
-      for (int a : pv[p]) for (int b : pv[p]) if (a != b) vadj[a].push_back(b);
-  for (auto& a : vadj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  });
+  // B B^T: the V-nodes of one pressure are connected to each other; row a collects through its own pressures (pv[a])
+  rows_for(nI, [&](int64_t a) {
+    if (lp.zero_diag[a]) return;
+    for (int p : pv[a])
+      for (int b : pv[p]) if (b != (int)a) vadj[a].push_back(b);
+    sort_unique(vadj[a]);
+  });
   lap_an("2");
   // --- nested dissection of the V-nodes
   NdCtx c;

@@ -558,14 +558,26 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
       }
     };
     if (par) parallel_for(n, classify, 4096); else for (int i = 0; i < n; i++) classify(i);
+    lap_an("12a classify");
     std::vector<int64_t> fptr((size_t)nf + 2, 0);
-    for (int64_t e = 0; e < nnz; e++) fptr[ent_front[e] + 1]++;
-    for (int s2 = 0; s2 <= nf; s2++) fptr[s2 + 1] += fptr[s2];
     P.ent_id.resize((size_t)nnz); P.ent_pos.resize((size_t)nnz); P.ent_w.resize((size_t)nnz);
     {
-      std::vector<int64_t> cur(fptr.begin(), fptr.end() - 1);
-      for (int64_t e = 0; e < nnz; e++) P.ent_id[cur[ent_front[e]]++] = (int32_t)e;
+      // stable counting sort in NB contiguous blocks of entries: a histogram per block, offsets per (front, block), fill
+      const int NB = par ? 16 : 1;
+      std::vector<std::vector<int64_t>> hist((size_t)NB, std::vector<int64_t>((size_t)nf + 1, 0));
+      auto blk = [&](int b) { return std::make_pair(nnz * b / NB, nnz * (b + 1) / NB); };
+      auto count = [&](int64_t b) { const auto r = blk((int)b); for (int64_t e = r.first; e < r.second; e++) hist[b][ent_front[e]]++; };
+      if (par) parallel_for(NB, count, 1); else count(0);
+      int64_t run = 0;
+      for (int s2 = 0; s2 <= nf; s2++) {
+        fptr[s2] = run;
+        for (int b = 0; b < NB; b++) { const int64_t c = hist[b][s2]; hist[b][s2] = run; run += c; }
+      }
+      fptr[(size_t)nf + 1] = run;
+      auto fill = [&](int64_t b) { const auto r = blk((int)b); for (int64_t e = r.first; e < r.second; e++) P.ent_id[hist[b][ent_front[e]]++] = (int32_t)e; };
+      if (par) parallel_for(NB, fill, 1); else fill(0);
     }
+    lap_an("12b count + fill");
     auto place = [&](int64_t s2) {
       const int sf = (int)s2;
       if (sf < nf) {
@@ -593,6 +605,7 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
       }
     };
     if (par) parallel_for(nf + 1, place, 8); else for (int s2 = 0; s2 <= nf; s2++) place(s2);
+    lap_an("12c place");
     for (int s2 = 0; s2 < nf; s2++) {
       const bool any = fptr[s2] < fptr[s2 + 1];
       P.fronts[s2].ent_begin = any ? (int32_t)fptr[s2] : 0;

@@ -18,9 +18,12 @@
 //     k_factor_level             multifrontal front: assemble, LU of the pivot block, triangular inverses, panel
 //                                products and the Schur update as workgroup-level tiled GEMMs (LDS staged)
 //     k_big_* / k_gemm_f64       wide supernodes spread over many workgroups; FP64 MFMA GEMMs with triangular masks
+//     k_big_pivot_blk            pivot pieces (<= 128 x 128): 32 x 32 diagonal blocks factored and inverted in registers,
+//                                everything else as MFMA tile products between LDS operands (k_big_pivot: scalar variant)
 //     k_repack                   packed L-side panels for the classes of the fused solve
-//     k_sblock_*                 separator block init / two-sided Householder / extraction
-//     k_dense_invert             in-place Gauss-Jordan with partial pivoting per block
+//     k_sblock_*                 separator block init / transformation + dropping in one pass (k_sblock_kept) / extraction
+//     k_gj_* / k_dense_invert    separator blocks: blocked Gauss-Jordan with partial pivoting (32 pivots per panel in registers,
+//                                rank-32 update on the matrix cores) / per-block Gauss-Jordan in LDS or global memory
 //     k_pull_sum*                deterministic assembly of the kept Schur entries
 //     k_solve_transposed, k_dot  bordered systems
 #include <hip/hip_runtime.h>

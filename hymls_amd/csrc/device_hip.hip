@@ -3026,6 +3026,86 @@ __global__ void __launch_bounds__(1024) k_gj_panel(int nb, int kb, double* __res
       if (c < bw) { W[i + (int64_t)nb * c] = pivot_row ? 0.0 : a[c]; A[i + (int64_t)nb * (kb + c)] = 0.0; }
   }
 }
+// the panel step for orders above GJ_MAX (up to GJ_BIG_MAX): the same result as k_gj_panel, with the panel LU done in a
+// global scratch copy (Lw = this block's part of R, free until k_gj_swap_scale writes it) instead of registers: 32 pivots x
+// three barriers, rows spread over the 1024 threads, the pivot row staged in LDS
+constexpr int GJ_BIG_MAX = 4096;
+__global__ void __launch_bounds__(1024) k_gj_panel_big(int nb, int kb, double* __restrict__ blocks, double* __restrict__ W0,
+                                                       double* __restrict__ Lw0, double* __restrict__ Inv0, int32_t* __restrict__ piv0, int32_t* flag) {
+  __shared__ double prow[GJB], red_v[16], LU[GJB * GJB], X[GJB * GJB];
+  __shared__ int red_i[16], s_perm[GJ_BIG_MAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x, nw = nt >> 6;
+  double* A = blocks + (int64_t)blockIdx.x * nb * nb;
+  double* W = W0 + (int64_t)blockIdx.x * nb * GJB;
+  double* Lw = Lw0 + (int64_t)blockIdx.x * nb * GJB;      // panel copy, column-major with leading dimension nb
+  double* Inv = Inv0 + (int64_t)blockIdx.x * GJB * GJB;
+  int32_t* piv = piv0 + (int64_t)blockIdx.x * nb;
+  const int bw = min(GJB, nb - kb);
+  for (int c = 0; c < bw; c++)
+    for (int i = tid; i < nb; i += nt) Lw[i + (int64_t)nb * c] = A[i + (int64_t)nb * (kb + c)];
+  for (int i = tid; i < nb; i += nt) s_perm[i] = i;
+  for (int t = tid; t < GJB * GJB; t += nt) LU[t] = 0.0;
+  __syncthreads();
+  for (int t = 0; t < bw; t++) {
+    const int kr = kb + t;
+    double* col = Lw + (int64_t)nb * t;
+    double v = -1.0; int idx = kr;
+    for (int i = kr + tid; i < nb; i += nt) { double a = fabs(col[i]); if (a != a) a = INFINITY; if (a > v) { v = a; idx = i; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    if (lane == 0) { red_v[wave] = v; red_i[wave] = idx; }
+    __syncthreads();
+    double pv = red_v[0]; int p = red_i[0];
+    for (int q = 1; q < nw; q++) {
+      const double ov = red_v[q]; const int oi = red_i[q];
+      if (ov > pv || (ov == pv && oi < p)) { pv = ov; p = oi; }
+    }
+    if (tid == 0 && (!(pv > 0.0) || !isfinite(pv))) atomicExch(flag, 1);
+    // rows kr and p of the panel copy change places; the new pivot row goes to LDS
+    if (tid < bw) {
+      const double a = Lw[kr + (int64_t)nb * tid], b = Lw[p + (int64_t)nb * tid];
+      Lw[kr + (int64_t)nb * tid] = b; Lw[p + (int64_t)nb * tid] = a;
+      prow[tid] = b;
+    }
+    if (tid == 0) { piv[kr] = p; const int tmp = s_perm[kr]; s_perm[kr] = s_perm[p]; s_perm[p] = tmp; }
+    __syncthreads();
+    const double ip = 1.0 / prow[t];
+    for (int i = kr + 1 + tid; i < nb; i += nt) {
+      const double l = col[i] * ip;
+      col[i] = l;
+      for (int c = t + 1; c < bw; c++) Lw[i + (int64_t)nb * c] -= l * prow[c];
+    }
+    __syncthreads();
+  }
+  for (int q = tid; q < bw * bw; q += nt) { const int r = q % bw, c = q / bw; LU[r + GJB * c] = Lw[(kb + r) + (int64_t)nb * c]; }
+  __syncthreads();
+  if (tid < GJB) {
+    const int j = tid;
+    if (j < bw) {
+      for (int r = 0; r < bw; r++) {
+        double sum = r == j ? 1.0 : 0.0;
+        for (int q = 0; q < r; q++) sum -= LU[r + GJB * q] * X[q * GJB + j];
+        X[r * GJB + j] = sum;
+      }
+      for (int r = bw - 1; r >= 0; r--) {
+        double sum = X[r * GJB + j];
+        for (int q = r + 1; q < bw; q++) sum -= LU[r + GJB * q] * X[q * GJB + j];
+        X[r * GJB + j] = sum / LU[r + GJB * r];
+      }
+    }
+    for (int r = 0; r < GJB; r++) Inv[r + GJB * j] = (r < bw && j < bw) ? X[r * GJB + j] : 0.0;
+  }
+  // W: the ORIGINAL panel (still in the block) in its permuted row order, pivot rows zero; then the panel columns are zeroed
+  for (int c = 0; c < bw; c++)
+    for (int i = tid; i < nb; i += nt) W[i + (int64_t)nb * c] = (i >= kb && i < kb + bw) ? 0.0 : A[s_perm[i] + (int64_t)nb * (kb + c)];
+  __syncthreads();
+  for (int c = 0; c < bw; c++)
+    for (int i = tid; i < nb; i += nt) A[i + (int64_t)nb * (kb + c)] = 0.0;
+}
 __global__ void __launch_bounds__(256) k_gj_swap_scale(int nb, int kb, double* __restrict__ blocks, const double* __restrict__ Inv0,
                                                        const int32_t* __restrict__ piv0, double* __restrict__ R0) {
   __shared__ double sInv[GJB * GJB];
@@ -3091,7 +3171,8 @@ static void dense_invert_blocked(int32_t nb, int32_t nblk, double* blocks, int32
   const int threads = std::min(1024, (nb + 63) / 64 * 64);
   for (int kb = 0; kb < nb; kb += GJB) {
     const int bw = std::min(GJB, nb - kb);
-    hipLaunchKernelGGL(k_gj_panel, dim3(nblk), dim3(threads), 0, g_stream, nb, kb, blocks, W, Inv, piv, flag);
+    if (nb <= GJ_MAX) hipLaunchKernelGGL(k_gj_panel, dim3(nblk), dim3(threads), 0, g_stream, nb, kb, blocks, W, Inv, piv, flag);
+    else hipLaunchKernelGGL(k_gj_panel_big, dim3(nblk), dim3(1024), 0, g_stream, nb, kb, blocks, W, R, Inv, piv, flag);
     hipLaunchKernelGGL(k_gj_swap_scale, dim3((nb + 255) / 256, nblk), dim3(256), 0, g_stream, nb, kb, blocks, Inv, piv, R);
     launch_check();
     gemm_f64<1, 0, 0>(blocks, nb, (int64_t)nb * nb, W, nb, (int64_t)nb * GJB, R, GJB, (int64_t)GJB * nb, nb, nb, bw, nblk);
@@ -3099,7 +3180,7 @@ static void dense_invert_blocked(int32_t nb, int32_t nblk, double* blocks, int32
   hipLaunchKernelGGL(k_gj_unpermute, dim3(nblk), dim3(256), 0, g_stream, nb, blocks, piv);
   launch_check();
 }
-bool dense_invert_blocked_order(int32_t nb) { return nb >= gj_blocked_min() && nb <= GJ_MAX; }
+bool dense_invert_blocked_order(int32_t nb) { return nb >= gj_blocked_min() && nb <= GJ_BIG_MAX; }
 void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag) {
   if (nb <= 0 || nblk <= 0) return;
   if (dense_invert_blocked_order(nb)) {

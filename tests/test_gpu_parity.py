@@ -504,11 +504,12 @@ def test_c_abi_from_plain_c(gpu_lib, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nb,nblk", [(1, 3), (10, 5), (64, 7), (88, 3), (100, 3), (160, 3), (191, 4), (392, 3), (791, 2), (1024, 1), (1100, 1)])
+@pytest.mark.parametrize("nb,nblk", [(1, 3), (10, 5), (64, 7), (88, 3), (100, 3), (160, 3), (191, 4), (392, 3), (791, 2), (1024, 1), (1100, 3), (2050, 1)])
 def test_separator_block_inversion_gpu(gpu_lib, nb, nblk):
     """hymls_mi_invert_blocks (Ifpack_DenseContainer::Compute in the reference, SchurPreconditioner.cpp:284-291): orders
     >= 160 take the blocked Gauss-Jordan route (32 pivots per panel, matrix-core update), orders that are no multiple of
-    32 included; 1100 exceeds its one-row-per-thread limit and takes the scalar kernel.  Checked against LAPACK (numpy):
+    32 included; above 1024 (one panel row per thread, in registers) the panel step works in a global scratch copy.  Checked
+    against LAPACK (numpy):
     |X A - I| small, and blocks that NEED the row interchanges (zero diagonal) are inverted as well."""
     A, tv = problem("Laplace", 8)
     P = product_prec(A, tv, xml_params("Laplace", 8, 4, 0), gpu_lib)

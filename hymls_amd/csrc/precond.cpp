@@ -50,10 +50,20 @@ void drop_by_value(const Csr& A, double tol, int kind, Csr& R) {
   R.n = A.n;
   R.rowptr.resize(A.n + 1);
   R.rowptr[0] = 0;
+  // A diagonal entry at rounding level (<= tol x the largest entry of its row) counts as the structural zero it is: the
+  // pressure diagonals of a reduced matrix cancel exactly on paper, and the ordering of the next level / the last-level
+  // solver tells pressures from velocities by a zero diagonal (as the reference does, MatrixUtils.cpp:1344-1352; its
+  // ComputeScaling uses the same 1e-14 relative threshold, SparseDirectSolver.cpp:632-664).  Summed on the GPU such a
+  // diagonal came out as 1.05e-14 next to entries of 1e3 and passed the absolute test: Darcy3D with separator length 16
+  // then paired velocities with the wrong nodes and the pivot-free factorisation grew by 1e13.
   dvec diag(A.n, 0.0);
   parallel_for(A.n, [&](int64_t i) {
-    for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++)
-      if (A.col[e] == i) diag[i] = A.val[e];
+    double d = 0.0, rmax = 0.0;
+    for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++) {
+      rmax = std::max(rmax, std::abs(A.val[e]));
+      if (A.col[e] == i) d = A.val[e];
+    }
+    diag[i] = std::abs(d) <= tol * rmax ? 0.0 : d;
   });
   // two passes over the rows (count, fill), rows in parallel
   auto row = [&](int64_t i, int32_t* col, double* val) {
@@ -65,7 +75,7 @@ void drop_by_value(const Csr& A, double tol, int kind, Csr& R) {
       const bool isd = j == i;
       if (isd && full_diag) continue;
       const double scal = isd ? 1.0 : std::max(std::abs(diag[i]), std::abs(diag[j]));
-      const double v = A.val[e];
+      const double v = isd ? diag[i] : A.val[e];
       if (std::abs(v) > scal * tol && std::abs(v) > tol) put(j, v);
       else if (isd && zero_diag) put(j, 0.0);
     }
@@ -419,6 +429,19 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   if (std::getenv("HYMLS_MI_VERBOSE")) {
     std::fprintf(stderr, "[hymls_mi] coarse solver: ordering + symbolic factorisation + plan %.2f s (host)\n", wall() - t_an);
     print_plan_stats(lu_->plan, "coarse solver", 1);
+  }
+  if (const char* dump = std::getenv("HYMLS_MI_DUMP_COARSE")) {
+    // development aid: the matrix that is factored (CSR) and the elimination order, as raw little-endian arrays
+    if (FILE* f = std::fopen(dump, "wb")) {
+      const int64_t hdr[3] = {n_, (int64_t)A.col.size(), (int64_t)lu_->plan.fronts.size()};
+      std::fwrite(hdr, sizeof(int64_t), 3, f);
+      std::fwrite(A.rowptr.data(), sizeof(int32_t), A.rowptr.size(), f);
+      std::fwrite(A.col.data(), sizeof(int32_t), A.col.size(), f);
+      std::fwrite(A.val.data(), sizeof(double), A.val.size(), f);
+      std::fwrite(lu_->plan.perm.data(), sizeof(int32_t), lu_->plan.perm.size(), f);
+      for (auto& F : lu_->plan.fronts) { const int32_t t[4] = {F.c0, F.w, F.ri, F.rs}; std::fwrite(t, sizeof(int32_t), 4, f); }
+      std::fclose(f);
+    }
   }
   lu_->members = {0};
   lu_->h_xoff = {0};

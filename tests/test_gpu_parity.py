@@ -238,7 +238,7 @@ def test_darcy3d_saddle_point_gpu(gpu_lib):
     assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-8
 
 
-def full_size_properties(gpu_lib, problem, n, levels, re=0.0, max_its=400, sizes=None):
+def full_size_properties(gpu_lib, problem, n, levels, re=0.0, max_its=400, sizes=None, sx=8):
     """Size-independent properties at a BASELINE size the oracle cannot reach: the operator is linear, reproducible
     bit for bit, maps pressure-free right-hand sides to divergence-free velocities (reference
     integration_tests.cpp:453-484, 1e-8), and right-preconditioned GMRES on the device (BaseSolver semantics,
@@ -247,7 +247,7 @@ def full_size_properties(gpu_lib, problem, n, levels, re=0.0, max_its=400, sizes
     import hymls_amd
     rp, ci, va = hymls_amd.generate_problem(problem, n, n, n, re=re, lib=gpu_lib)
     tv = hymls_amd.generate_testvector(rp, ci, va, lib=gpu_lib)
-    P = hymls_amd.Preconditioner((rp, ci, va), xml_params("Stokes-C", n, 8, levels, partitioner="Skew Cartesian"), testVector=tv, lib=gpu_lib)
+    P = hymls_amd.Preconditioner((rp, ci, va), xml_params("Stokes-C", n, sx, levels, partitioner="Skew Cartesian"), testVector=tv, lib=gpu_lib)
     P.Compute()
     if sizes:
         assert [s[1] for s in P.level_sizes()] == sizes
@@ -565,3 +565,14 @@ def test_recompute_keeps_the_coarse_plan_gpu(gpu_lib, eq, n, sx, levels, cx):
     F = product_prec(A, tv, xml_params(eq, n, sx, levels, cx, "Skew Cartesian" if eq == "Stokes-C" else "Cartesian"), gpu_lib)
     assert rel_diff(P.ApplyInverse(b), F.ApplyInverse(b)) < 1e-12
     assert P.NumInitialize() == 1 and P.NumCompute() == 3
+
+
+@pytest.mark.gpu
+def test_darcy_separator_length_16_rounding_level_pressure_diagonals_gpu(gpu_lib):
+    """Darcy3D 64^3 with separator length 16, two-level: summed on the GPU, 42 of the 199 pressure diagonals of the reduced
+    matrix come out as 1.05e-14 (next to entries of 1e3) instead of the exact zeros a CPU summation gives.  The ordering
+    of the last-level solver tells pressures from velocities by their zero diagonal (reference MatrixUtils.cpp:1344-1352),
+    so those have to count as zeros -- they once made the pivot-free factorisation grow by 1e13 (Compute returned -4).
+    The CPU oracle needs 73 GMRES iterations for this problem."""
+    its = full_size_properties(gpu_lib, "Darcy", 64, 1, max_its=100, sx=16, sizes=[4 * 64 ** 3, 3528])
+    assert its <= 80

@@ -264,6 +264,8 @@ def main():
             bt = torch.from_numpy(b)
         else:
             bt = b
+        if bt.dim() > 1:
+            bt = bt[0]          # (--nvec > 1: the Krylov check uses the first column)
         rhs = P.MatVec(bt).clone()
         barrier(); t0 = time.perf_counter()
         xs = S.ApplyInverse(rhs)

@@ -249,6 +249,9 @@ struct KeptD {
   const int32_t* gptr; const int32_t* glink; const int32_t* goff; const int64_t* lboff; const int32_t* lblen;
 };
 void sblock_kept(const KeptD& K, const double* tv, const double* sblock, double* out, int64_t out_stride, int32_t nbc);
+// false when the three separator-length vectors of the fused kernel exceed the LDS of a workgroup (separator blocks of order
+// 6000+: separator length 32): the caller then takes the two-pass route, sblock_transform + sblock_extract
+bool sblock_kept_fits(int32_t nS, int32_t ngl);
 // batched dense inverse with partial pivoting: nblk blocks of order nb (col-major), in place
 void dense_invert(int32_t nb, int32_t nblk, double* blocks, int32_t* flag);
 // true where dense_invert() takes the blocked (32 pivots at a time, matrix-core update) route: such groups are worth a

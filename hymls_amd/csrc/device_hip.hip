@@ -2812,6 +2812,10 @@ __global__ void __launch_bounds__(256) k_sblock_kept(KeptD K, const double* __re
     }
   }
 }
+bool sblock_kept_fits(int32_t nS, int32_t ngl) {
+  static const bool two_pass = std::getenv("HYMLS_MI_SBLOCK_TWO_PASS") != nullptr;   // (tests: force the fallback on small problems)
+  return !two_pass && (size_t)(3 * (int64_t)nS + 4 * (int64_t)ngl) * sizeof(double) + 1024 <= LDS_LIMIT_BYTES;
+}
 void sblock_kept(const KeptD& K, const double* tv, const double* sblock, double* out, int64_t out_stride, int32_t nbc) {
   if (K.nS <= 0 || K.ngl <= 0 || nbc <= 0) return;
   const size_t shm = (size_t)(3 * K.nS + 4 * K.ngl) * sizeof(double);

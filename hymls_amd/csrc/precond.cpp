@@ -1666,9 +1666,15 @@ void LevelSolver::compute() {
       if (C.pat.nS == 0) continue;
       if (!direct_schur_) {
         // orthogonal transformation + dropping: only the kept entries are formed, in one read pass over the block
-        const dev::KeptD K{C.pat.nS, C.ngl, C.d_lgptr, C.d_glink, C.d_goff, C.d_lboff, C.d_lblen};
-        dev::sblock_kept(K, C.d_tvloc + (size_t)b0 * C.pat.nS, C.lu.batch.sblock, d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size,
-                         C.ext_size, nbc);
+        if (dev::sblock_kept_fits(C.pat.nS, C.ngl)) {
+          const dev::KeptD K{C.pat.nS, C.ngl, C.d_lgptr, C.d_glink, C.d_goff, C.d_lboff, C.d_lblen};
+          dev::sblock_kept(K, C.d_tvloc + (size_t)b0 * C.pat.nS, C.lu.batch.sblock, d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size,
+                           C.ext_size, nbc);
+        } else {
+          // separator blocks too large for the fused kernel's LDS vectors: two-sided Householder in place, then extraction
+          dev::sblock_transform(C.pat.nS, C.ngl, C.d_lgptr, C.d_tvloc + (size_t)b0 * C.pat.nS, C.lu.batch.sblock, nbc);
+          dev::sblock_extract(C.pat.nS, C.ext_size, C.d_pick, C.lu.batch.sblock, d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size, C.ext_size, nbc);
+        }
       } else {
         dev::sblock_extract(C.pat.nS, C.ext_size, C.d_pick, C.lu.batch.sblock,
                             d_ext_ + C.ext_base + (int64_t)b0 * C.ext_size, C.ext_size, nbc);

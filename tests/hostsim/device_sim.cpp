@@ -404,6 +404,7 @@ void sblock_transform(int32_t nS, int32_t ng, const int32_t* gptr, const double*
 }
 
 // kept entries of the transformed block: the simulator transforms a copy and reads the kept positions
+bool sblock_kept_fits(int32_t, int32_t) { return true; }
 void sblock_kept(const KeptD& K, const double* tv, const double* sblock, double* out, int64_t out_stride, int32_t nbc) {
   const int nS = K.nS, ngl = K.ngl;
   std::vector<double> T((size_t)nS * nS);

@@ -576,3 +576,28 @@ def test_darcy_separator_length_16_rounding_level_pressure_diagonals_gpu(gpu_lib
     The CPU oracle needs 73 GMRES iterations for this problem."""
     its = full_size_properties(gpu_lib, "Darcy", 64, 1, max_its=100, sx=16, sizes=[4 * 64 ** 3, 3528])
     assert its <= 80
+
+
+@pytest.mark.gpu
+def test_two_pass_separator_transform_fallback_gpu(gpu_lib, tmp_path):
+    """Separator blocks whose three vectors exceed the LDS of the fused transform + dropping kernel (order 6000+: separator
+    length 32) take the two-sided Householder passes + extraction instead.  Forced here on a small problem (the switch is
+    read once per process, so the check runs in a child process) and compared with the oracle."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from common import problem, xml_params, oracle_prec, product_prec, rel_diff
+        import hymls_amd
+        lib = hymls_amd.load_library()
+        A, tv = problem("Stokes-C", 16)
+        P = product_prec(A, tv, xml_params("Stokes-C", 16, 4, 2, 2, "Skew Cartesian"), lib)
+        O = oracle_prec(A, tv, "Stokes-C", 16, 4, 2, 2, partitioner="Skew Cartesian")
+        b = np.random.default_rng(5).uniform(-1, 1, A.shape[0])
+        d = rel_diff(P.ApplyInverse(b), O.apply_inverse(b))
+        print("rel diff", d)
+        assert d < 1e-8
+    """ % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, HYMLS_MI_SBLOCK_TWO_PASS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -322,7 +322,7 @@ def main():
                                        "cavity": "Navier-Stokes-like Jacobian Re=%g (Stokes3D + central convection, synthesised)" % args.re}[args.problem],
                                       nx, ny, nz, N_global if sharded else N_local, levels + 1, levels, sx, args.nvec),
                        "parallelism": "1 GPU" if world == 1 and not sharded else (
-                           "sharded: %dx%dx%d boxes of %dx%dx%d cells, one per GPU; halo + V-sum exchange over %s, RCCL ranks = %d"
+                           "sharded: %dx%dx%d boxes of %dx%dx%d cells, one per GPU; halo + V-sum exchange over %s, ranks = %d"
                            % (px, py, pz, nx // px, ny // py, nz // pz,
                               "the built-in RCCL transport (ncclSend/ncclRecv groups on the library's stream)" if native
                               else "torch.distributed (%s) callbacks" % backend, world) if sharded else

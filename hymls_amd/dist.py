@@ -17,16 +17,21 @@ from .api import A2A_FN, ALLOC_FN, _Comm
 
 
 def rank_grid(world):
-    """boxes of the grid per direction for `world` ranks: 2 -> (2,1,1), 4 -> (2,2,1), 8 -> (2,2,2) ...
-    (repeated halving x, y, z like the reference's CreatePIDMap, src/HYMLS_BasePartitioner.cpp:361-586)"""
-    g = [1, 1, 1]
-    d = 0
-    w = world
+    """boxes of the grid per direction for `world` ranks: 2 -> (2,1,1), 4 -> (2,2,1), 8 -> (2,2,2), 6 -> (3,2,1), 12 -> (3,2,2) ...
+    The prime factors of `world`, largest first, go to the direction with the fewest boxes so far (powers of two: the repeated
+    halving x, y, z of the reference's CreatePIDMap, src/HYMLS_BasePartitioner.cpp:361-586).  The library checks that the
+    subdomains of every level divide evenly over the boxes (hymls_mi_set_comm)."""
+    assert world >= 1
+    factors, w, p = [], world, 2
     while w > 1:
-        assert w % 2 == 0, "number of ranks must be a power of two"
-        g[d % 3] *= 2
-        w //= 2
-        d += 1
+        while w % p == 0:
+            factors.append(p)
+            w //= p
+        p += 1
+    g = [1, 1, 1]
+    for f in sorted(factors, reverse=True):
+        d = min(range(3), key=lambda k: (g[k], k))
+        g[d] *= f
     return tuple(g)
 
 

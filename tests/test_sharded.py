@@ -77,3 +77,17 @@ def test_sharded_bordered_matches_one_rank(hostsim_lib, world, eq, nx, ny, nz, s
     border of the Schur system travels with the halo / hand-off exchanges.  Same (X, S) as on one rank."""
     res = run_worker(world, (eq, nx, ny, nz, sx, levels, cx, part), "hostsim", 29580 + world, env_extra={"HYMLS_TEST_BORDER": "1"})
     assert res["cover_ok"] and res["rel_err"] < 1e-12 and res["border_err"] < 1e-10
+
+
+@pytest.mark.parametrize("world,args", [
+    (3, ("Stokes-C", 48, 16, 16, 8, 1, -1, "Skew Cartesian")),
+    (6, ("Laplace", 24, 16, 8, 4, 1, -1, "Cartesian")),
+])
+def test_rank_counts_that_are_no_power_of_two(world, args):
+    """rank_grid spreads the prime factors of the world size over x, y, z (3 -> 3x1x1, 6 -> 3x2x1): the sharded ApplyInverse
+    equals the one-rank one (the reference's CreatePIDMap accepts any processor count too, BasePartitioner.cpp:361-586)."""
+    from hymls_amd.dist import rank_grid
+    assert rank_grid(3) == (3, 1, 1) and rank_grid(6) == (3, 2, 1) and rank_grid(8) == (2, 2, 2) and rank_grid(16) == (4, 2, 2)
+    res = run_worker(world, args, "hostsim", 29660 + world, timeout=800)
+    assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
+    assert res["rel_err"] < 1e-10

@@ -925,6 +925,13 @@ void LevelSolver::initialize() {
 }
 
 void LevelSolver::build_classes() {
+  const bool verbose_bc = std::getenv("HYMLS_MI_VERBOSE") != nullptr && level_ == 0;
+  double t_bc = wall();
+  auto lap_bc = [&](const char* what) {
+    if (!verbose_bc) return;
+    std::fprintf(stderr, "[hymls_mi] rank %d level %d:   classes / %-22s %.2f s\n", comm_->rank, level_, what, wall() - t_bc);
+    t_bc = wall();
+  };
   const int n = K_.n;
   const int nsd = (int)hm_.sd.size();
   const int nsep = n2_ + ngs_;
@@ -1074,6 +1081,7 @@ void LevelSolver::build_classes() {
     }, 1);
     HYMLS_CHECK(mismatch == 0, -3, "two different subdomain patterns share one 64-bit hash");
   }
+  lap_bc("patterns + class lookup");
   for (size_t c = first_new; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
     const size_t ne = C.pat.col.size();
@@ -1084,11 +1092,13 @@ void LevelSolver::build_classes() {
       ivec().swap(v);
     }, 64);
   }
+  lap_bc("entry source lists");
   // ---- pass 2: symbolic analysis of every class (independent: in parallel)
   parallel_for((int64_t)(cls_.size() - first_new), [&](int64_t k) {
     Cls& C = *cls_[first_new + k];
     C.lu.plan = analyse_class(C.pat, std::getenv("HYMLS_MI_LEAF_SIZE") ? std::atoi(std::getenv("HYMLS_MI_LEAF_SIZE")) : LEAF_SIZE, MAX_WIDTH);
   }, 1);
+  lap_bc("symbolic analysis");
   // ---- pass 3: interior numbering in elimination order, subdomain by subdomain
   n1_ = 0;
   in_perm_.clear();
@@ -1105,6 +1115,7 @@ void LevelSolver::build_classes() {
     n1_ += C.pat.nI;
   }
   for (int k = 0; k < n2_; k++) in_perm_.push_back(sep_row_[k]);
+  lap_bc("interior numbering");
   if (std::getenv("HYMLS_MI_VERBOSE")) {
     std::fprintf(stderr, "[hymls_mi] rank %d level %d: local nodes %d subdomains %zu (+%zu halo) classes %zu n1 %d n2 %d ghost sep %d\n",
                  comm_->rank, level_, n, my_sds_.size(), halo_sds_.size(), cls_.size(), n1_, n2_, ngs_);

@@ -74,7 +74,9 @@ struct Params {
 // static chunks over [0, n) on up to 16 host threads (setup-time integer work only)
 template <class Fn>
 void parallel_for(int64_t n, Fn fn, int64_t grain = 256) {
-  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / grain}));
+  // host threads of the setup: 16 by default (the share of a GPU on an 8-GPU node), HYMLS_MI_HOST_THREADS overrides
+  static const int64_t cap = std::getenv("HYMLS_MI_HOST_THREADS") ? std::max(1, std::atoi(std::getenv("HYMLS_MI_HOST_THREADS"))) : 16;
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), cap, n / grain}));
   if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
   std::vector<std::thread> th;
   std::exception_ptr err = nullptr;

@@ -26,7 +26,8 @@ class _Params(C.Structure):
         "nx", "ny", "nz", "dim", "equations", "dof", "sx", "sy", "sz", "cx", "cy", "cz", "levels",
         "partitioner", "retain_nodes", "retain_pressures", "link_velocities", "link_retained",
         "fix_pressure_level", "nfix")] + [("fix_gid", C.c_int32 * 4), ("variable_type", C.c_int32 * 8),
-                                         ("retain_xyz", C.c_int32 * 3), ("retain_at_level", C.c_int32 * 8)]
+                                         ("retain_xyz", C.c_int32 * 3), ("retain_at_level", C.c_int32 * 8),
+                                         ("retain_at_level_xyz", (C.c_int32 * 3) * 8), ("periodic", C.c_int32 * 3)]
 
 
 _I32P = C.POINTER(C.c_int32)
@@ -109,6 +110,7 @@ def load_library(path=None):
         "hymls_mi_generate_problem": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64,
                                                 _I32P, _I64P, _I32P, _I32P, _F64P]),
         "hymls_mi_generate_testvector": (C.c_int, [C.c_int64, _I32P, _I32P, _F64P, _F64P]),
+        "hymls_mi_drop_by_value": (C.c_int, [C.c_int64, _I32P, _I32P, _F64P, C.c_double, C.c_int, _I64P, _I32P, _I32P, _F64P]),
         "hymls_mi_last_error": (C.c_char_p, [H]),
         "hymls_mi_destroy": (None, [H]),
     }
@@ -212,6 +214,24 @@ def generate_testvector(rowptr, col, val, lib=None):
     tv = np.empty(rowptr.size - 1, np.float64)
     lib.hymls_mi_generate_testvector(rowptr.size - 1, _i32(rowptr), _i32(col), _f64(val), _f64(tv))
     return tv
+
+
+def drop_by_value(A, tol=1e-14, kind="RelDropDiag", lib=None):
+    """MatrixUtils::DropByValue as Compute applies it (include/hymls_mi.h: hymls_mi_drop_by_value); A a scipy matrix"""
+    import scipy.sparse as sp
+    lib = lib or load_library()
+    A = A.tocsr()
+    A.sort_indices()
+    rp, ci, va = (np.ascontiguousarray(A.indptr, np.int32), np.ascontiguousarray(A.indices, np.int32),
+                  np.ascontiguousarray(A.data, np.float64))
+    k = {"RelDropDiag": 0, "RelZeroDiag": 1, "RelFullDiag": 2}[kind]
+    nnz = C.c_int64()
+    ierr = lib.hymls_mi_drop_by_value(A.shape[0], _i32(rp), _i32(ci), _f64(va), tol, k, C.byref(nnz), None, None, None)
+    if ierr:
+        raise HymlsError(ierr, "drop_by_value")
+    orp, oci, ova = np.empty(A.shape[0] + 1, np.int32), np.empty(max(nnz.value, 1), np.int32), np.empty(max(nnz.value, 1))
+    lib.hymls_mi_drop_by_value(A.shape[0], _i32(rp), _i32(ci), _f64(va), tol, k, C.byref(nnz), _i32(orp), _i32(oci), _f64(ova))
+    return sp.csr_matrix((ova[:nnz.value], oci[:nnz.value], orp), shape=A.shape)
 
 
 _EQ = {"Laplace": 0, "Stokes-C": 1}
@@ -329,6 +349,11 @@ class Preconditioner:
             p.retain_xyz[d] = prec.get("Retain Nodes (%s)" % ax, -1)
         for l in range(8):
             p.retain_at_level[l] = prec.get("Retain Nodes at Level %d" % l, -1)
+            for d, ax in enumerate("xyz"):
+                p.retain_at_level_xyz[l][d] = prec.get("Retain Nodes at Level %d (%s)" % (l, ax), -1)
+        perio = int(prob.get("Periodicity", sum((1 << d) for d, ax in enumerate("xyz") if prob.get("%s-periodic" % ax, False))))
+        for d in range(3):
+            p.periodic[d] = (perio >> d) & 1
         p.retain_pressures = prob.get("Retained Pressure Nodes", -1)
         p.link_velocities = int(prec.get("Eliminate Velocities Together", True))
         p.link_retained = int(prec.get("Eliminate Retained Nodes Together", True))

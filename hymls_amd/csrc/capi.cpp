@@ -59,6 +59,8 @@ void hymls_mi_default_params(hymls_mi_params* p) {
   p->link_velocities = 1; p->link_retained = 1; p->fix_pressure_level = 1; p->nfix = 0;
   for (int d = 0; d < 3; d++) p->retain_xyz[d] = -1;
   for (int l = 0; l < 8; l++) p->retain_at_level[l] = -1;
+  for (int l = 0; l < 8; l++) for (int d = 0; d < 3; d++) p->retain_at_level_xyz[l][d] = -1;
+  for (int d = 0; d < 3; d++) p->periodic[d] = 0;
 }
 
 static Params convert(const hymls_mi_params* q) {
@@ -75,6 +77,8 @@ static Params convert(const hymls_mi_params* q) {
   p.retain = q->retain_nodes;
   for (int d = 0; d < 3; d++) p.retain_xyz[d] = q->retain_xyz[d];
   for (int l = 0; l < 8; l++) p.retain_at_level[l] = q->retain_at_level[l];
+  for (int l = 0; l < 8; l++) for (int d = 0; d < 3; d++) p.retain_at_level_xyz[l][d] = q->retain_at_level_xyz[l][d];
+  for (int d = 0; d < 3; d++) p.perio[d] = q->periodic[d] != 0 && d < p.dim;
   p.level = 0;
   p.set_retain();
   p.levels = q->levels;
@@ -567,6 +571,26 @@ int hymls_mi_generate_testvector(int64_t n, const int32_t* rowptr, const int32_t
       if (val[e] != 0.0 && colind[e] != i) { is_diag = false; break; }
     tv[i] = is_diag ? 0.0 : 1.0;
   }
+  return 0;
+}
+
+int hymls_mi_drop_by_value(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val, double tol, int kind,
+                           int64_t* nnz_out, int32_t* rowptr_out, int32_t* col_out, double* val_out) {
+  if (n < 0 || !rowptr || !nnz_out || kind < 0 || kind > 2 || (rowptr[n] > 0 && (!col || !val))) return -2;
+  try {
+    Csr A;
+    A.n = (int32_t)n;
+    A.rowptr.assign(rowptr, rowptr + n + 1);
+    A.col.assign(col, col + rowptr[n]);
+    A.val.assign(val, val + rowptr[n]);
+    const Csr R = drop_by_value(A, tol, kind);
+    *nnz_out = R.nnz();
+    if (rowptr_out) {
+      std::copy(R.rowptr.begin(), R.rowptr.end(), rowptr_out);
+      if (col_out) std::copy(R.col.begin(), R.col.end(), col_out);
+      if (val_out) std::copy(R.val.begin(), R.val.end(), val_out);
+    }
+  } catch (...) { return -3; }
   return 0;
 }
 

@@ -87,15 +87,22 @@ int group_exchange(RcclTransport* T, const char* send, const int64_t* scnt, char
   bool any = false;
   for (int q = 0; q < T->size; q++) any |= (q != T->rank) && (scnt[q] > 0 || rcnt[q] > 0);
   if (any) NCCL_OK(api().GroupStart());
+  // an error inside the open group must not leave the communicator in group mode (every later exchange would hang or
+  // fail opaquely): remember the first failure, skip the rest, close the group, then report
+  ncclResult_t first = ncclSuccess;
   for (int q = 0; q < T->size; q++) {
     if (q == T->rank) { self_so = so; self_ro = ro; }
-    else {
-      if (scnt[q] > 0) NCCL_OK(api().Send(send + so * eb, (size_t)(scnt[q] * eb), ncclInt8, q, T->comm, stream));
-      if (rcnt[q] > 0) NCCL_OK(api().Recv(recv + ro * eb, (size_t)(rcnt[q] * eb), ncclInt8, q, T->comm, stream));
+    else if (first == ncclSuccess) {
+      if (scnt[q] > 0) first = api().Send(send + so * eb, (size_t)(scnt[q] * eb), ncclInt8, q, T->comm, stream);
+      if (first == ncclSuccess && rcnt[q] > 0) first = api().Recv(recv + ro * eb, (size_t)(rcnt[q] * eb), ncclInt8, q, T->comm, stream);
     }
     so += scnt[q]; ro += rcnt[q];
   }
-  if (any) NCCL_OK(api().GroupEnd());
+  if (any) {
+    const ncclResult_t end = api().GroupEnd();
+    if (first == ncclSuccess) first = end;
+  }
+  if (first != ncclSuccess) { T->error = std::string("RCCL: ") + api().GetErrorString(first); return -1; }
   const int64_t ns = scnt[T->rank];
   if (ns != rcnt[T->rank]) { T->error = "all-to-all: a rank's segment to itself differs in its send and receive counts"; return -1; }
   if (ns > 0) HIP_OK(hipMemcpyAsync(recv + self_ro * eb, send + self_so * eb, (size_t)(ns * eb), hipMemcpyDeviceToDevice, stream));

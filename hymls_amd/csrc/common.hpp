@@ -48,6 +48,8 @@ struct Params {
   int sx = 4, sy = -1, sz = -1, cx = -1, cy = -1, cz = -1;
   int rx = -1, ry = -1, rz = -1;   // "Retain Nodes" of THIS level (see set_retain)
   int retain = -1, retain_xyz[3] = {-1, -1, -1}, retain_at_level[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  int retain_at_level_xyz[8][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};
+  bool perio[3] = {false, false, false};   // "x-periodic", "y-periodic", "z-periodic"
   int level = 0;                   // partitioner level (0 = finest)
   int levels = 1;
   int partitioner = 0;  // 0 Cartesian, 1 Skew Cartesian
@@ -55,12 +57,15 @@ struct Params {
   bool link_velocities = true, link_retained = true;
   std::vector<int32_t> vtype;    // per dof
   std::vector<int32_t> fix_gid;  // "Fix GID n"
-  // rx, ry, rz of this level: "(x|y|z)" wins, then "Retain Nodes at Level <level>", then "Retain Nodes"
-  // (reference src/HYMLS_BasePartitioner.cpp:108-137)
+  // rx, ry, rz of this level: "Retain Nodes at Level <level> (x|y|z)" wins, then "Retain Nodes (x|y|z)", then
+  // "Retain Nodes at Level <level>", then "Retain Nodes" (reference src/HYMLS_BasePartitioner.cpp:108-137)
   void set_retain() {
     const int at = level < 8 ? retain_at_level[level] : -1;
     int* r[3] = {&rx, &ry, &rz};
-    for (int d = 0; d < 3; d++) *r[d] = retain_xyz[d] != -1 ? retain_xyz[d] : (at != -1 ? at : retain);
+    for (int d = 0; d < 3; d++) {
+      const int atd = level < 8 ? retain_at_level_xyz[level][d] : -1;
+      *r[d] = atd != -1 ? atd : (retain_xyz[d] != -1 ? retain_xyz[d] : (at != -1 ? at : retain));
+    }
   }
   Params next_level() const {  // SetNextLevelParameters (BasePartitioner.cpp:321-346)
     Params q = *this;

@@ -404,6 +404,7 @@ __device__ inline void lds_lu_and_inverses(double* S, int w, double* xv, int* s_
                                            unsigned long long* s_ml, unsigned long long* s_mu) {
   const int tid = threadIdx.x, nt = blockDim.x;
   block_absmax(S, w, w, true, true, s_m0);
+  __syncthreads();   // every wave has finished scanning S before the first elimination step writes into it
   for (int k = 0; k < w; k++) {
     const double piv = S[k + w * k];
     if (tid == 0 && (piv == 0.0 || !isfinite(piv))) *s_bad |= 1;
@@ -824,6 +825,7 @@ __global__ void __launch_bounds__(PIVB_T) k_big_pivot_blk(double* __restrict__ A
   for (Idx2 q(tid, W, PIVB_T); q.j < W; q.next()) S[q.i + W * q.j] = (q.i < w && q.j < w) ? A[q.i + ld * q.j] : (q.i == q.j ? 1.0 : 0.0);
   __syncthreads();
   block_absmax(S, W, w, true, true, &s_m0);
+  __syncthreads();   // (the scan of S is complete before wave 0 overwrites the first diagonal block)
   double umax = 0.0;                     // largest |u_ij| this thread has produced
   const int r = lane & 31;
   for (int kblk = 0; kblk < nbk; kblk++) {

@@ -54,6 +54,10 @@ typedef struct hymls_mi_params {
   int32_t retain_xyz[3];        /* "Retain Nodes (x|y|z)" (-1: unset) */
   int32_t retain_at_level[8];   /* "Retain Nodes at Level k", k = 0.. (-1: unset); precedence as the reference,
                                    src/HYMLS_BasePartitioner.cpp:108-137: (x|y|z), then at-level, then "Retain Nodes" */
+  int32_t retain_at_level_xyz[8][3]; /* "Retain Nodes at Level k (x|y|z)" (-1: unset): wins over "Retain Nodes (x|y|z)",
+                                   src/HYMLS_BasePartitioner.cpp:112-124 */
+  int32_t periodic[3];          /* "x-periodic", "y-periodic", "z-periodic" of the "Problem" list (0|1), or the bits of
+                                   "Periodicity" (GaleriExt::PERIO_Flag: 1 x, 2 y, 4 z), src/HYMLS_BasePartitioner.cpp:49-62 */
 } hymls_mi_params;
 
 /* fill *p with the reference defaults (everything -1 / default flags). */
@@ -227,6 +231,21 @@ int hymls_mi_generate_problem(int problem, int nx, int ny, int nz, double a, dou
 /* create_testvector (reference src/HYMLS_MainUtils.cpp:208-258). */
 int hymls_mi_generate_testvector(int64_t nrows, const int32_t* rowptr, const int32_t* colind,
                                  const double* val, double* tv);
+
+/* MatrixUtils::DropByValue (reference src/HYMLS_MatrixUtils.cpp:1011-1227) as Compute applies it to the reduced
+ * matrix of a level (kind 0 = RelDropDiag, src/HYMLS_SchurPreconditioner.cpp:548-549), to the Schur complement of a
+ * one-level method (1 = RelZeroDiag) and in the last-level solver (2 = RelFullDiag, src/HYMLS_CoarseSolver.cpp:141-142):
+ * an entry stays if |a_ij| > tol * max(|a_ii|, |a_jj|) and |a_ij| > tol (diagonal entries: |a_ii| > tol).
+ * ONE RULE ON TOP OF THE REFERENCE'S: a diagonal entry with |a_ii| <= tol * max_j |a_ij| is taken for the structural
+ * zero it is on paper before anything else is decided (the relative threshold of the reference's ComputeScaling,
+ * src/HYMLS_SparseDirectSolver.cpp:632-664).  Pressure diagonals of a reduced matrix cancel exactly in a CPU summation
+ * but come out as ~1e-14 x rowmax from the GPU's summation order; the orderings tell pressures from velocities by a zero
+ * diagonal (src/HYMLS_MatrixUtils.cpp:1344-1352) and must not take those for velocities.  The rule only fits
+ * tol = HYMLS_SMALL_ENTRY (1e-14); the oracle has the same rule behind a switch (oracle/hymls.py:
+ * ROUNDING_LEVEL_DIAGONAL_IS_ZERO) so that both sides can be compared under it.
+ * Host arrays, square CSR with local column indices; two-call protocol (rowptr_out == NULL: count only, *nnz_out). */
+int hymls_mi_drop_by_value(int64_t n, const int32_t* rowptr, const int32_t* col, const double* val, double tol, int kind,
+                           int64_t* nnz_out, int32_t* rowptr_out, int32_t* col_out, double* val_out);
 
 const char* hymls_mi_last_error(const hymls_mi_t* h);
 void hymls_mi_destroy(hymls_mi_t* h);

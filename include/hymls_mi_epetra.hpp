@@ -65,16 +65,35 @@ class Preconditioner : public Ifpack_Preconditioner {
     const std::string eq = prob.get("Equations", std::string("Laplace"));
     p_.equations = eq == "Laplace" ? 0 : (eq == "Stokes-C" ? 1 : -1);
     p_.dof = prob.get("Degrees of Freedom", -1);
-    p_.sx = prec.get("Separator Length", 4);
-    p_.sy = prec.get("Separator Length (y)", -1); p_.sz = prec.get("Separator Length (z)", -1);
-    p_.cx = prec.get("Coarsening Factor", -1);
-    p_.cy = prec.get("Coarsening Factor (y)", -1); p_.cz = prec.get("Coarsening Factor (z)", -1);
+    // "(x|y|z)" spellings win over the plain key (reference src/HYMLS_BasePartitioner.cpp:64-102); isParameter first,
+    // so that reading a key never writes a default into the caller's list under a name the reference would not write
+    p_.sx = prec.isParameter("Separator Length (x)") ? prec.get("Separator Length (x)", -1) : prec.get("Separator Length", 4);
+    p_.sy = prec.isParameter("Separator Length (y)") ? prec.get("Separator Length (y)", -1) : -1;
+    p_.sz = prec.isParameter("Separator Length (z)") ? prec.get("Separator Length (z)", -1) : -1;
+    p_.cx = prec.isParameter("Coarsening Factor (x)") ? prec.get("Coarsening Factor (x)", -1)
+                                                      : (prec.isParameter("Coarsening Factor") ? prec.get("Coarsening Factor", -1) : -1);
+    p_.cy = prec.isParameter("Coarsening Factor (y)") ? prec.get("Coarsening Factor (y)", -1) : -1;
+    p_.cz = prec.isParameter("Coarsening Factor (z)") ? prec.get("Coarsening Factor (z)", -1) : -1;
     p_.levels = prec.get("Number of Levels", 1);
     p_.partitioner = prec.get("Partitioner", std::string("Cartesian")) == "Skew Cartesian" ? 1 : 0;
-    p_.retain_nodes = prec.get("Retain Nodes", -1);
-    p_.retain_xyz[0] = prec.get("Retain Nodes (x)", -1); p_.retain_xyz[1] = prec.get("Retain Nodes (y)", -1); p_.retain_xyz[2] = prec.get("Retain Nodes (z)", -1);
-    for (int l = 0; l < 8; l++) p_.retain_at_level[l] = prec.get("Retain Nodes at Level " + std::to_string(l), -1);
-    p_.retain_pressures = prec.get("Retained Pressure Nodes", -1);
+    // the four spellings of "Retain Nodes" with the reference's precedence (src/HYMLS_BasePartitioner.cpp:108-137):
+    // "Retain Nodes at Level k (x|y|z)" > "Retain Nodes (x|y|z)" > "Retain Nodes at Level k" > "Retain Nodes"
+    static const char* const axis[3] = {" (x)", " (y)", " (z)"};
+    auto opt = [&prec](const std::string& key) { return prec.isParameter(key) ? prec.get(key, -1) : -1; };
+    p_.retain_nodes = opt("Retain Nodes");
+    for (int d = 0; d < 3; d++) p_.retain_xyz[d] = opt(std::string("Retain Nodes") + axis[d]);
+    for (int l = 0; l < 8; l++) {
+      const std::string at = "Retain Nodes at Level " + std::to_string(l);
+      p_.retain_at_level[l] = opt(at);
+      for (int d = 0; d < 3; d++) p_.retain_at_level_xyz[l][d] = opt(at + axis[d]);
+    }
+    // read from the "Problem" list, as the reference does (src/HYMLS_BasePartitioner.cpp:224,244,263)
+    p_.retain_pressures = prob.isParameter("Retained Pressure Nodes") ? prob.get("Retained Pressure Nodes", -1) : -1;
+    // "x-periodic" .. or the bit mask "Periodicity" (src/HYMLS_BasePartitioner.cpp:49-62)
+    int perio = (prob.get("x-periodic", false) ? 1 : 0) | (p_.dim > 1 && prob.get("y-periodic", false) ? 2 : 0) |
+                (p_.dim > 2 && prob.get("z-periodic", false) ? 4 : 0);
+    perio = prob.get("Periodicity", perio);
+    for (int d = 0; d < 3; d++) p_.periodic[d] = (perio >> d) & 1;
     p_.link_velocities = prec.get("Eliminate Velocities Together", true) ? 1 : 0;
     p_.link_retained = prec.get("Eliminate Retained Nodes Together", true) ? 1 : 0;
     p_.fix_pressure_level = prec.get("Fix Pressure Level", true) ? 1 : 0;
@@ -106,10 +125,12 @@ class Preconditioner : public Ifpack_Preconditioner {
       if (ierr) return keep_error(ierr);
     }
     // SetMatrix with an unchanged pattern: the library kept its ordering (reference src/HYMLS_Preconditioner.hpp:244-254)
-    if (hymls_mi_is_initialized(h_)) return 0;
+    if (hymls_mi_is_initialized(h_)) return 0;   // (PassMatrix cleared matrix_dirty_)
     return keep_error(hymls_mi_initialize(h_));
   }
-  bool IsInitialized() const { return h_ && hymls_mi_is_initialized(h_); }
+  // false after SetMatrix until the new matrix has been handed over: the reference's SetMatrix sets initialized_ = false
+  // (src/HYMLS_Preconditioner.hpp:244-254), so that Compute() initialises by itself (Preconditioner.cpp:403-409)
+  bool IsInitialized() const { return h_ && !matrix_dirty_ && hymls_mi_is_initialized(h_); }
 
   int Compute() {
     if (!IsInitialized()) {   // reference src/HYMLS_Preconditioner.cpp:403-409: "I'll do it for you"
@@ -207,6 +228,8 @@ class Preconditioner : public Ifpack_Preconditioner {
   }
 
   // SetMatrix (reference src/HYMLS_Preconditioner.hpp:244-254): same pattern, new values; Initialize / Compute again
+  // (IsInitialized() is false from here until the next Initialize; the old factors stay usable until then, as in the
+  // reference, which leaves computed_ alone)
   void SetMatrix(Teuchos::RCP<const Epetra_CrsMatrix> matrix) { matrix_ = matrix; matrix_dirty_ = true; }
 
   // the message behind the last non-zero return code (HYMLS::Exception::what() in the reference)

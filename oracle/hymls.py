@@ -74,10 +74,28 @@ def householder_row(v):
     return v / nrm
 
 
-def drop_by_value(A, droptol=SMALL, kind="RelZeroDiag"):
+# Switch for comparisons with the product under ITS rule (off = the reference's literal DropByValue): a diagonal entry
+# at rounding level, |a_ii| <= droptol x the largest entry of row i, counts as the structural zero it is on paper (the
+# relative threshold of the reference's ComputeScaling, src/HYMLS_SparseDirectSolver.cpp:632-664).  The product applies
+# it in its drop_by_value (hymls_amd/csrc/precond.cpp) because the pressure diagonals of a reduced matrix, which cancel
+# exactly on the CPU, come out as ~1e-14 x rowmax from the GPU's summation order and must not be taken for velocities by
+# the zero-diagonal test of the orderings (src/HYMLS_MatrixUtils.cpp:1344-1352).  The rule only fits droptol =
+# HYMLS_SMALL_ENTRY: any larger tolerance would drop legitimately small diagonals.
+ROUNDING_LEVEL_DIAGONAL_IS_ZERO = False
+
+
+def drop_by_value(A, droptol=SMALL, kind="RelZeroDiag", rounding_level_diagonal_is_zero=None):
     """MatrixUtils::DropByValue (src/HYMLS_MatrixUtils.cpp:1011-1212)."""
     A = A.tocsr()
     n = A.shape[0]
+    if ROUNDING_LEVEL_DIAGONAL_IS_ZERO if rounding_level_diagonal_is_zero is None else rounding_level_diagonal_is_zero:
+        A = A.copy()
+        A.sort_indices()
+        rows_ = np.repeat(np.arange(n), np.diff(A.indptr))
+        rmax = np.zeros(n)
+        np.maximum.at(rmax, rows_, np.abs(A.data))
+        tiny = (rows_ == A.indices) & (np.abs(A.data) <= droptol * rmax[rows_])
+        A.data[tiny] = 0.0
     rel = kind in ("Relative", "RelDropDiag", "RelZeroDiag", "RelFullDiag")
     abs_diag = kind in ("RelDropDiag", "RelZeroDiag", "RelFullDiag", "AbsZeroDiag", "AbsFullDiag", "Absolute")
     zero_diag = kind in ("RelZeroDiag", "AbsZeroDiag")

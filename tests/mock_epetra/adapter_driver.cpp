@@ -70,6 +70,20 @@ int main() {
     err = 0;
     for (int v = 0; v < 3; v++) for (int i = 0; i < N; i++) err = std::max(err, std::abs(2.0 * Y[v][i] - X[v][i]));
     REQUIRE(err < 1e-10);
+    // SetMatrix, then Compute() WITHOUT Initialize(): the reference's SetMatrix clears initialized_
+    // (src/HYMLS_Preconditioner.hpp:244-254) and Compute() initialises by itself (Preconditioner.cpp:403-409); the new
+    // values must be the ones that are factored
+    Teuchos::RCP<Epetra_CrsMatrix> K4 = make_matrix(0, n, map, 4.0);
+    P->SetMatrix(K4);
+    REQUIRE(!prec->IsInitialized());
+    REQUIRE(prec->Compute() == 0 && prec->IsInitialized() && prec->IsComputed() && prec->NumCompute() == 3);
+    REQUIRE(op->ApplyInverse(B, Y) == 0);
+    err = 0;
+    for (int v = 0; v < 3; v++) for (int i = 0; i < N; i++) err = std::max(err, std::abs(4.0 * Y[v][i] - X[v][i]));
+    std::printf("SetMatrix -> Compute without Initialize: max |4 P^{-1} K x - x| = %.2e\n", err);
+    REQUIRE(err < 1e-10);
+    P->SetMatrix(K2);
+    REQUIRE(prec->Compute() == 0);
     // bordered: [K V; V' 0] [x; s] = [y; t] solved exactly on one level (reference :278-378)
     Teuchos::RCP<Epetra_MultiVector> V = Teuchos::rcp(new Epetra_MultiVector(map, 1));
     for (int i = 0; i < N; i++) (*V)[0][i] = rnd();
@@ -94,7 +108,7 @@ int main() {
     Teuchos::RCP<Epetra_CrsMatrix> K = make_matrix(0, n, map, -1.0);   // positive definite
     Teuchos::RCP<Teuchos::ParameterList> params = Teuchos::rcp(new Teuchos::ParameterList());
     params->sublist("Problem").set("Equations", "Laplace").set("Dimension", 3).set("nx", n);
-    params->sublist("Preconditioner").set("Separator Length", 4).set("Number of Levels", 1);
+    params->sublist("Preconditioner").set("Separator Length (x)", 4).set("Separator Length (y)", 4).set("Separator Length (z)", 4).set("Number of Levels", 1);   // the "(x|y|z)" spellings, reference src/HYMLS_BasePartitioner.cpp:68-73
     Teuchos::RCP<Epetra_Vector> tv = Teuchos::rcp(new Epetra_Vector(map));
     tv->PutScalar(1.0);
     HYMLS_MI::Preconditioner P(K, params, tv);

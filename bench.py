@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 
-def cpu_baseline(problem, re, n, sx, levels, seconds_budget=30.0):
+def cpu_baseline(problem, re, n, sx, levels, seconds_budget=30.0, gpu_lib_ok=True):
     """The compiled CPU oracle (oracle/cpu/hymls_cpu.cpp through oracle/cpu_oracle.py: the reference's algorithm as the
     reference performs it -- per-subdomain sparse LU with the F-matrix ordering, dense Schur parts, Householder, dgetrf
     blocks, serial exact coarse LU -- OpenMP over subdomains, built here with -O3 -march=native; kind 'port') timed on
@@ -62,12 +62,37 @@ def cpu_baseline(problem, re, n, sx, levels, seconds_budget=30.0):
             O.apply_inverse(b)
             reps += 1
         rate[nt] = (A.shape[0] / ((time.time() - t0) / reps), reps)
+    # Krylov iteration count on the sample ("must equal the CPU path's on the same matrix"): right-preconditioned
+    # GMRES, zero initial guess, b = K x_ex, 1e-8 -- with the CPU oracle here, and with the product on the SAME sample
+    # (same matrix, same right-hand side) on the GPU
+    from oracle import krylov
+    x_ex = np.random.default_rng(1).uniform(-1, 1, A.shape[0])
+    rhs = A @ x_ex
+    O.set_threads(cores)
+    _, its_cpu, res_cpu = krylov.gmres(lambda v: A @ v, rhs, O.apply_inverse, tol=1e-8, maxit=300)
+    its_gpu, res_gpu = None, None
+    if gpu_lib_ok:
+        import hymls_amd
+        prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": n, "ny": n, "nz": n},
+               "Preconditioner": {"Separator Length": sx, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
+        A.sort_indices()
+        Pg = hymls_amd.Preconditioner(A, prm, testVector=tv)
+        Pg.Compute()
+        Sg = hymls_amd.Solver(Pg, Pg, {"Krylov Method": "GMRES", "Iterative Solver": {"Convergence Tolerance": 1e-8, "Maximum Iterations": 300, "Num Blocks": 300}})
+        xg = Sg.ApplyInverse(torch.from_numpy(rhs).cuda())
+        its_gpu = Sg.getNumIter()
+        res_gpu = float(np.linalg.norm(rhs - A @ xg.cpu().numpy()) / np.linalg.norm(rhs))
+        del Sg, Pg
     return {"value": rate[cores][0], "unit": "DoF/s", "cores": cores, "kind": "port",
             "value_1_core": rate[1][0],
+            "krylov_iterations_cpu": its_cpu, "krylov_iterations_gpu_same_sample": its_gpu,
+            "krylov_true_relative_residual_cpu": res_cpu, "krylov_true_relative_residual_gpu_same_sample": res_gpu,
             "sample": "compiled CPU oracle (g++ -O3 -march=native -fopenmp; sparse LU per subdomain, %d nonzeros in L+U; serial SuperLU coarse "
                       "solve) ApplyInverse on %s %d^3 = %d DoF, Skew Cartesian sx=%d, Number of Levels=%d, levels %s; %d applies at %d "
-                      "threads, %d at 1 thread, after a %.1f s setup on %d threads"
-                      % (O.nnz_factors(), problem, n, A.shape[0], sx, levels, O.level_sizes(), rate[cores][1], cores, rate[1][1], t_setup, cores)}
+                      "threads, %d at 1 thread, after a %.1f s setup on %d threads; right-preconditioned GMRES to 1e-8 on this sample: "
+                      "%d iterations with the CPU oracle, %s with the product on the GPU (same matrix, same right-hand side)"
+                      % (O.nnz_factors(), problem, n, A.shape[0], sx, levels, O.level_sizes(), rate[cores][1], cores, rate[1][1], t_setup, cores,
+                         its_cpu, its_gpu)}
 
 
 PROBLEM = {"stokes": "Stokes", "darcy": "Darcy", "cavity": "Cavity"}
@@ -89,9 +114,10 @@ def main():
                     help="right-hand sides per ApplyInverse (Epetra_MultiVector columns); > 1: the factors are streamed once per "
                          "group of 4 columns, value = DoF x vectors / s")
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent copies instead of the sharded problem")
-    ap.add_argument("--krylov", action="store_true",
-                    help="after the timed region: solve K x = b (b = K x_ex) with right-preconditioned GMRES on the device "
-                         "(hymls_amd.Solver, relative residual 1e-8) and report the iteration count and time")
+    ap.add_argument("--krylov", dest="krylov", action="store_true", default=True,
+                    help="(default) after the timed region: solve K x = b (b = K x_ex) with right-preconditioned GMRES on the "
+                         "device (hymls_amd.Solver, relative residual 1e-8) and report the iteration count and time")
+    ap.add_argument("--no-krylov", dest="krylov", action="store_false")
     ap.add_argument("--krylov-restart", type=int, default=100, help="GMRES restart length ('Num Blocks')")
     ap.add_argument("--share-gpu", action="store_true",
                     help="REHEARSAL ONLY: all ranks use cuda:0 (with --backend gloo, staged through the host); "
@@ -175,21 +201,21 @@ def main():
         comm = RcclComm(local_rank, lib=lib) if native else TorchComm(dev)
         P = hymls_amd.Preconditioner(None, prm, device=local_rank, lib=lib, comm=comm, rank_grid=(px, py, pz))
         if native:
-            # the built-in transport checks itself on every rank before any work is sharded over it; if a rank fails, all
-            # ranks switch to the callback transport (still the sharded problem, and config.parallelism says which one ran)
-            bad = torch.tensor([1.0 if P.CommSelfTest() != 0 else 0.0], dtype=torch.float64, device=dev)
+            # the built-in transport checks itself on every rank before any work is sharded over it.  A failure on any rank
+            # ends the run with a non-zero exit code: the callback transport is a different code path and has to be asked
+            # for (--transport torch), never switched to behind the reader's back
+            self_rc = P.CommSelfTest()
+            bad = torch.tensor([1.0 if self_rc != 0 else 0.0], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)
             if bad.item() > 0:
-                sys.stderr.write("bench.py: built-in RCCL transport failed its self-test on some rank: torch.distributed transport\n")
-                native = False
-                err = transport_selftest(dev, backend)
-                if err:
-                    sys.stderr.write("bench.py: sharded transport self-test failed on rank %d (%s); no fallback\n" % (rank, err))
-                    dist.destroy_process_group()
-                    sys.exit(3)
-                comm = TorchComm(dev)
-                P = hymls_amd.Preconditioner(None, prm, device=local_rank, lib=lib, comm=comm, rank_grid=(px, py, pz))
+                sys.stderr.write("bench.py: the built-in RCCL transport failed its self-test (rank %d: %s); no fallback -- "
+                                 "rerun with --transport torch to use the torch.distributed callbacks\n"
+                                 % (rank, "failed here with code %d" % self_rc if self_rc != 0 else "ok here, failed on another rank"))
+                del P
+                comm.close()
+                dist.destroy_process_group()
+                sys.exit(3)
         t0 = time.time()
         req = P.RequiredRows()
         rows = hymls_amd.generate_problem(PROBLEM[args.problem], nx, ny, nz, re=args.re, gids=req, lib=lib)
@@ -348,7 +374,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample: a 48^3 grid has no third level with sx = cx = 8 (and the serial coarse LU of a larger
             # two-level sample takes minutes to set up, as it does for the reference): two-level sample
-            out["cpu_baseline"] = cpu_baseline(args.problem, args.re, args.cpu_n, sx, min(levels, 1))
+            out["cpu_baseline"] = cpu_baseline(args.problem, args.re, args.cpu_n, sx, min(levels, 1), gpu_lib_ok=not args.hostsim)
         else:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -68,6 +68,11 @@ def load_library(path=None):
         "hymls_mi_create": (C.c_int, [C.POINTER(H), C.POINTER(_Params), C.c_int]),
         "hymls_mi_set_matrix_csr": (C.c_int, [H, C.c_int64, _I32P, _I32P, _F64P]),
         "hymls_mi_set_comm": (C.c_int, [H, C.POINTER(_Comm), C.c_int, C.c_int, C.c_int]),
+        "hymls_mi_rank_grid": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "hymls_mi_device_alloc": (C.c_void_p, [H, C.c_int64]),
+        "hymls_mi_device_free": (None, [H, C.c_void_p]),
+        "hymls_mi_copy_to_host": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int64]),
+        "hymls_mi_copy_to_device": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int64]),
         "hymls_mi_rccl_unique_id": (C.c_int, [C.c_char_p]),
         "hymls_mi_rccl_comm_init": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
         "hymls_mi_rccl_comm_destroy": (None, [C.c_void_p]),
@@ -202,10 +207,14 @@ def generate_testvector_rows(gids, rowptr, col, val):
     """create_testvector for a list of rows with global column ids (0 for rows that only have a
     diagonal entry, 1 otherwise; reference src/HYMLS_MainUtils.cpp:208-258)."""
     gids = np.asarray(gids)
-    rows = np.repeat(np.arange(gids.size), np.diff(rowptr))
-    off = (val != 0.0) & (col != gids[rows])
-    tv = np.zeros(gids.size)
-    tv[np.unique(rows[off])] = 1.0
+    rowptr = np.asarray(rowptr)
+    n = gids.size
+    tv = np.zeros(n)
+    if n == 0 or rowptr[-1] == 0:
+        return tv
+    off = (val != 0.0) & (col != np.repeat(gids, np.diff(rowptr)))
+    nonempty = np.flatnonzero(np.diff(rowptr) > 0)      # (reduceat needs strictly increasing starts)
+    tv[nonempty] = np.logical_or.reduceat(off, rowptr[nonempty])
     return tv
 
 

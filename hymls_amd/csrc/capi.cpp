@@ -150,6 +150,42 @@ int hymls_mi_set_comm(hymls_mi_t* h, const hymls_mi_comm* c, int px, int py, int
   API_END(h)
 }
 
+int hymls_mi_rank_grid(int size, int* px, int* py, int* pz) {
+  if (size < 1 || !px || !py || !pz) return -2;
+  std::vector<int> f;
+  for (int w = size, p = 2; w > 1; p++) while (w % p == 0) { f.push_back(p); w /= p; }
+  std::sort(f.rbegin(), f.rend());
+  int g[3] = {1, 1, 1};
+  for (int v : f) {
+    int d = 0;
+    for (int k = 1; k < 3; k++) if (g[k] < g[d]) d = k;
+    g[d] *= v;
+  }
+  *px = g[0]; *py = g[1]; *pz = g[2];
+  return 0;
+}
+
+void* hymls_mi_device_alloc(hymls_mi_t* h, int64_t bytes) {
+  if (!h || bytes < 0) return nullptr;
+  try { dev::bind(h->ctx); return dev::alloc((size_t)bytes); } catch (const std::exception& e) { h->err = e.what(); return nullptr; }
+}
+void hymls_mi_device_free(hymls_mi_t* h, void* p) {
+  if (!h || !p) return;
+  try { dev::bind(h->ctx); dev::free(p); } catch (...) {}
+}
+int hymls_mi_copy_to_host(hymls_mi_t* h, void* host_dst, const void* device_src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes && (!host_dst || !device_src))) return -2;
+  API_BEGIN
+  dev::d2h(host_dst, device_src, (size_t)bytes);
+  API_END(h)
+}
+int hymls_mi_copy_to_device(hymls_mi_t* h, void* device_dst, const void* host_src, int64_t bytes) {
+  if (!h || bytes < 0 || (bytes && (!device_dst || !host_src))) return -2;
+  API_BEGIN
+  dev::h2d(device_dst, host_src, (size_t)bytes);
+  API_END(h)
+}
+
 int hymls_mi_rccl_unique_id(char* id128) {
   if (!id128) return -2;
   try { rccl_unique_id(id128); } catch (const hymls::Error& e) { return e.code; } catch (...) { return -3; }

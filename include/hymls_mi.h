@@ -95,6 +95,17 @@ typedef struct hymls_mi_comm {
 /* rank r owns the box (r % px, (r / px) % py, r / (px*py)) of the grid, as the reference's
  * CreatePIDMap (src/HYMLS_BasePartitioner.cpp:361-586); call before any matrix is set.  Collective. */
 int hymls_mi_set_comm(hymls_mi_t* h, const hymls_mi_comm* comm, int px, int py, int pz);
+/* boxes per direction for `size` ranks: 2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2, 6 -> 3x2x1 (the prime factors of size, largest
+ * first, go to the direction with the fewest boxes so far; for powers of two the repeated halving x, y, z of the
+ * reference's CreatePIDMap, src/HYMLS_BasePartitioner.cpp:361-586). */
+int hymls_mi_rank_grid(int size, int* px, int* py, int* pz);
+/* helpers for transports that move device segments through host memory (an MPI library without GPU support,
+ * include/hymls_mi_mpi.h): memory on the handle's device, and copies that are ordered on the handle's stream and
+ * complete when the call returns. */
+void* hymls_mi_device_alloc(hymls_mi_t* h, int64_t bytes);
+void hymls_mi_device_free(hymls_mi_t* h, void* p);
+int hymls_mi_copy_to_host(hymls_mi_t* h, void* host_dst, const void* device_src, int64_t bytes);
+int hymls_mi_copy_to_device(hymls_mi_t* h, void* device_dst, const void* host_src, int64_t bytes);
 /* The built-in transport: RCCL send/recv groups on the handle's stream (hymls_amd/csrc/comm_rccl.cpp) -- the
  * "RCCL halo/separator exchange over xGMI replacing the Epetra MPI Import/Export" (reference
  * src/HYMLS_Preconditioner.cpp:978-979,1050-1052, src/HYMLS_SchurPreconditioner.cpp:1076-1078).  One exchange of the

@@ -13,12 +13,25 @@
 // the Epetra / Teuchos / Ifpack declarations used below, and tests/test_epetra_adapter.py compiles this header
 // against them and drives Initialize / Compute / ApplyInverse through it.
 //
-// One process: the matrix rows are the GIDs 0..N-1 in order (the reference's linear map on one rank).  A distributed
-// Epetra application maps onto the sharded entry points of hymls_mi.h (hymls_mi_set_comm + hymls_mi_required_rows +
-// hymls_mi_set_matrix_rows); this adapter returns -99 when Comm().NumProc() > 1.
+// One process: the matrix rows are the GIDs 0..N-1 in order (the reference's linear map on one rank).
+//
+// Distributed (Comm().NumProc() > 1, compiled with -DHYMLS_MI_HAVE_MPI, one rank per GPU; the reference's deployment,
+// src/main.cpp:48-67): the matrix may live on ANY one-to-one row map.  The adapter does what the reference's Initialize /
+// Compute do with their importer (src/HYMLS_Preconditioner.cpp:326-336,428-432):
+//   * rank r of the communicator takes box r of hymls_mi_rank_grid (the reference's CreatePIDMap layout);
+//   * hymls_mi_required_rows gives the overlapping row map; an Epetra_Import from the matrix' row map brings those rows
+//     (and the test vector) to the rank, hymls_mi_set_matrix_rows hands them to the library;
+//   * ApplyInverse imports B from the operator's map to the library's ownership (hymls_mi_owned_rows: interiors of the
+//     rank's subdomains + the separators it owns) and exports X back, so OperatorDomainMap() == OperatorRangeMap() ==
+//     K.RowMatrixRowMap() as in the reference (src/HYMLS_Preconditioner.hpp:182-186) and the Krylov loop is unchanged;
+//   * the exchanges inside Compute / ApplyInverse run over the transport named by the "Preconditioner" key
+//     "MI Transport": "RCCL" (default: the library's ncclSend/ncclRecv groups on its stream, bootstrapped over MPI) or
+//     "MPI" (MPI_Alltoallv with host staging: any MPI library, several ranks per GPU, the test-only host simulator);
+//     include/hymls_mi_mpi.h holds both.
 #ifndef HYMLS_MI_EPETRA_HPP
 #define HYMLS_MI_EPETRA_HPP
 
+#include <cstdlib>
 #include <ostream>
 #include <stdexcept>
 #include <string>
@@ -26,6 +39,7 @@
 
 #include "Epetra_Comm.h"
 #include "Epetra_CrsMatrix.h"
+#include "Epetra_Import.h"
 #include "Epetra_Map.h"
 #include "Epetra_MultiVector.h"
 #include "Epetra_RowMatrix.h"
@@ -36,6 +50,10 @@
 #include "Teuchos_RCP.hpp"
 
 #include "hymls_mi.h"
+#ifdef HYMLS_MI_HAVE_MPI   // (the counterpart of Epetra's own EPETRA_MPI switch)
+#include "Epetra_MpiComm.h"
+#include "hymls_mi_mpi.h"
+#endif
 
 namespace HYMLS_MI {
 
@@ -51,7 +69,7 @@ class Preconditioner : public Ifpack_Preconditioner {
       throw std::runtime_error("HYMLS_MI::Preconditioner needs an Epetra_CrsMatrix");
     if (params_ != Teuchos::null) SetParameters(*params_);
   }
-  virtual ~Preconditioner() { if (h_) hymls_mi_destroy(h_); }
+  virtual ~Preconditioner() { Release(); }
 
   // ---- Ifpack_Preconditioner (reference src/HYMLS_Preconditioner.hpp:93-140)
   // the keys of the "Problem" and "Preconditioner" sublists that BasePartitioner::SetParameters and
@@ -103,30 +121,59 @@ class Preconditioner : public Ifpack_Preconditioner {
       if (!prec.isParameter(key)) break;
       p_.fix_gid[p_.nfix++] = prec.get(key, -1);
     }
+    transport_ = prec.get("MI Transport", std::string("RCCL"));
     have_params_ = true;
-    if (h_) { hymls_mi_destroy(h_); h_ = 0; }   // new parameters: everything is rebuilt by the next Initialize
+    Release();   // new parameters: everything is rebuilt by the next Initialize
     return 0;
   }
 
   int Initialize() {
     if (!have_params_) return fail(-1, "SetParameters has not been called");
-    if (matrix_->Comm().NumProc() > 1)
-      return fail(-99, "distributed Epetra maps: use the sharded entry points of hymls_mi.h (INTEGRATION.md)");
+    distributed_ = matrix_->Comm().NumProc() > 1;
+#ifdef HYMLS_MI_HAVE_MPI
+    // (tests: one rank that takes the sharded path and exchanges with itself through the transport)
+    if (std::getenv("HYMLS_MI_FORCE_SHARDED") && dynamic_cast<const Epetra_MpiComm*>(&matrix_->Comm())) distributed_ = true;
+#endif
     int ierr = 0;
     const bool fresh = !h_;
     if (fresh) {
       ierr = hymls_mi_create(&h_, &p_, device_);
       if (ierr) return keep_error(ierr);
+      if (distributed_) {
+        ierr = AttachComm();
+        if (ierr) return ierr;
+      }
     }
-    ierr = PassMatrix();
+    ierr = distributed_ ? PassMatrixRows() : PassMatrix();
     if (ierr) return keep_error(ierr);
     if (fresh && testVector_ != Teuchos::null) {
-      ierr = hymls_mi_set_testvector(h_, testVector_->Values());
+      if (distributed_) {   // one value per row given: the test vector on the overlapping map
+        Epetra_Vector tv(*overlapMap_);
+        if (tv.Import(*testVector_, *rowImporter_, Insert)) return fail(-3, "import of the test vector failed");
+        ierr = hymls_mi_set_testvector(h_, tv.Values());
+      } else {
+        ierr = hymls_mi_set_testvector(h_, testVector_->Values());
+      }
       if (ierr) return keep_error(ierr);
     }
     // SetMatrix with an unchanged pattern: the library kept its ordering (reference src/HYMLS_Preconditioner.hpp:244-254)
     if (hymls_mi_is_initialized(h_)) return 0;   // (PassMatrix cleared matrix_dirty_)
-    return keep_error(hymls_mi_initialize(h_));
+    ierr = hymls_mi_initialize(h_);
+    if (ierr) return keep_error(ierr);
+    if (distributed_) {
+      // the library's ownership (interiors of this rank's subdomains + the separators it owns) as an Epetra map, and
+      // the plan between it and the operator's map
+      int64_t n = 0;
+      ierr = hymls_mi_owned_rows(h_, &n, 0);
+      if (ierr) return keep_error(ierr);
+      std::vector<int32_t> own((size_t)n + 1);
+      ierr = hymls_mi_owned_rows(h_, &n, own.data());
+      if (ierr) return keep_error(ierr);
+      std::vector<int> g(own.begin(), own.begin() + n);
+      ownedMap_ = Teuchos::rcp(new Epetra_Map(-1, (int)n, g.data(), 0, matrix_->Comm()));
+      vecImporter_ = Teuchos::rcp(new Epetra_Import(*ownedMap_, matrix_->RowMap()));
+    }
+    return 0;
   }
   // false after SetMatrix until the new matrix has been handed over: the reference's SetMatrix sets initialized_ = false
   // (src/HYMLS_Preconditioner.hpp:244-254), so that Compute() initialises by itself (Preconditioner.cpp:403-409)
@@ -158,7 +205,17 @@ class Preconditioner : public Ifpack_Preconditioner {
     X.ExtractView(&x, &ldx);
     Y.ExtractView(&y, &ldy);
     if (x == y) return fail(-2, "ApplyInverse: X and Y must not alias");
-    return keep_error(hymls_mi_apply_inverse(h_, x, ldx, y, ldy, X.NumVectors(), /*on_device=*/0));
+    if (!distributed_) return keep_error(hymls_mi_apply_inverse(h_, x, ldx, y, ldy, X.NumVectors(), /*on_device=*/0));
+    // operator's map -> the library's ownership and back (the reference imports into its overlapping map and exports
+    // the solution the same way, src/HYMLS_Preconditioner.cpp:978-979,1050-1052)
+    Epetra_MultiVector Xo(*ownedMap_, X.NumVectors()), Yo(*ownedMap_, X.NumVectors());
+    if (Xo.Import(X, *vecImporter_, Insert)) return fail(-3, "ApplyInverse: import of the right-hand side failed");
+    Xo.ExtractView(&x, &ldx);
+    Yo.ExtractView(&y, &ldy);
+    const int ierr = hymls_mi_apply_inverse(h_, x, ldx, y, ldy, X.NumVectors(), /*on_device=*/0);
+    if (ierr) return keep_error(ierr);
+    if (Y.Export(Yo, *vecImporter_, Insert)) return fail(-3, "ApplyInverse: export of the solution failed");
+    return 0;
   }
 
   const Epetra_RowMatrix& Matrix() const { return *matrix_; }
@@ -199,9 +256,22 @@ class Preconditioner : public Ifpack_Preconditioner {
     if (V == Teuchos::null) { have_border_ = false; return keep_error(hymls_mi_set_border(h_, 0, 0, 0, 0, 0, 0)); }
     double *v = 0, *w = 0;
     int ldv = 0, ldw = 0;
-    V->ExtractView(&v, &ldv);
-    if (W != Teuchos::null) W->ExtractView(&w, &ldw);
     const int m = V->NumVectors();
+    // distributed: every rank passes the rows it owns (hymls_mi_owned_rows)
+    Teuchos::RCP<Epetra_MultiVector> Vo, Wo;
+    if (distributed_) {
+      Vo = Teuchos::rcp(new Epetra_MultiVector(*ownedMap_, m));
+      if (Vo->Import(*V, *vecImporter_, Insert)) return fail(-3, "SetBorder: import of V failed");
+      Vo->ExtractView(&v, &ldv);
+      if (W != Teuchos::null) {
+        Wo = Teuchos::rcp(new Epetra_MultiVector(*ownedMap_, m));
+        if (Wo->Import(*W, *vecImporter_, Insert)) return fail(-3, "SetBorder: import of W failed");
+        Wo->ExtractView(&w, &ldw);
+      }
+    } else {
+      V->ExtractView(&v, &ldv);
+      if (W != Teuchos::null) W->ExtractView(&w, &ldw);
+    }
     std::vector<double> c;
     if (C != Teuchos::null) {
       c.resize((size_t)m * m);
@@ -217,13 +287,23 @@ class Preconditioner : public Ifpack_Preconditioner {
     if (!IsComputed()) return fail(-1, "The preconditioner has not yet been computed.");
     double *y = 0, *x = 0;
     int ldy = 0, ldx = 0;
-    Y.ExtractView(&y, &ldy);
-    X.ExtractView(&x, &ldx);
+    Teuchos::RCP<Epetra_MultiVector> Yo, Xo;
+    if (distributed_) {
+      Yo = Teuchos::rcp(new Epetra_MultiVector(*ownedMap_, Y.NumVectors()));
+      Xo = Teuchos::rcp(new Epetra_MultiVector(*ownedMap_, Y.NumVectors()));
+      if (Yo->Import(Y, *vecImporter_, Insert)) return fail(-3, "ApplyInverse: import of the right-hand side failed");
+      Yo->ExtractView(&y, &ldy);
+      Xo->ExtractView(&x, &ldx);
+    } else {
+      Y.ExtractView(&y, &ldy);
+      X.ExtractView(&x, &ldx);
+    }
     for (int k = 0; k < Y.NumVectors(); k++) {
       const int ierr = hymls_mi_apply_inverse_bordered(h_, y + (size_t)k * ldy, T.A() + (size_t)k * T.LDA(), x + (size_t)k * ldx,
                                                        S.A() + (size_t)k * S.LDA(), 0);
       if (ierr) return keep_error(ierr);
     }
+    if (distributed_ && X.Export(*Xo, *vecImporter_, Insert)) return fail(-3, "ApplyInverse: export of the solution failed");
     return 0;
   }
 
@@ -254,6 +334,66 @@ class Preconditioner : public Ifpack_Preconditioner {
     matrix_dirty_ = false;
     return hymls_mi_set_matrix_csr(h_, n, rp.data(), ci.data(), va.data());
   }
+  // the rows this rank has to hold (hymls_mi_required_rows = the reference's overlapping map) brought here by an
+  // Epetra_Import from the matrix' row map, as reference src/HYMLS_Preconditioner.cpp:326-336,428-432
+  int PassMatrixRows() {
+    if (overlapMap_ == Teuchos::null) {
+      int64_t n = 0;
+      int ierr = hymls_mi_required_rows(h_, &n, 0);
+      if (ierr) return ierr;
+      std::vector<int32_t> req((size_t)n + 1);
+      ierr = hymls_mi_required_rows(h_, &n, req.data());
+      if (ierr) return ierr;
+      std::vector<int> g(req.begin(), req.begin() + n);
+      overlapMap_ = Teuchos::rcp(new Epetra_Map(-1, (int)n, g.data(), 0, matrix_->Comm()));
+      rowImporter_ = Teuchos::rcp(new Epetra_Import(*overlapMap_, matrix_->RowMap()));
+    }
+    Epetra_CrsMatrix Kov(Copy, *overlapMap_, 0);
+    if (Kov.Import(*matrix_, *rowImporter_, Insert)) return fail(-3, "import of the overlapping matrix rows failed");
+    if (Kov.FillComplete(matrix_->DomainMap(), matrix_->RangeMap())) return fail(-3, "FillComplete of the overlapping matrix failed");
+    const int n = Kov.NumMyRows();
+    std::vector<int32_t> gid(n), rp(n + 1, 0), ci;
+    std::vector<double> va;
+    ci.reserve((size_t)Kov.NumMyNonzeros());
+    va.reserve((size_t)Kov.NumMyNonzeros());
+    for (int i = 0; i < n; i++) {
+      gid[i] = overlapMap_->GID(i);
+      int len = 0; double* v = 0; int* c = 0;
+      if (Kov.ExtractMyRowView(i, len, v, c)) return fail(-2, "ExtractMyRowView failed");
+      for (int k = 0; k < len; k++) { ci.push_back(Kov.GCID(c[k])); va.push_back(v[k]); }
+      rp[i + 1] = (int32_t)ci.size();
+    }
+    matrix_dirty_ = false;
+    return hymls_mi_set_matrix_rows(h_, n, gid.data(), rp.data(), ci.data(), va.data());
+  }
+  // one rank = one GPU = one box of the grid; the transport the parameter list names
+  int AttachComm() {
+#ifdef HYMLS_MI_HAVE_MPI
+    const Epetra_MpiComm* mc = dynamic_cast<const Epetra_MpiComm*>(&matrix_->Comm());
+    if (!mc) return fail(-2, "distributed matrix whose communicator is not an Epetra_MpiComm");
+    int px = 1, py = 1, pz = 1;
+    hymls_mi_rank_grid(mc->NumProc(), &px, &py, &pz);
+    int ierr;
+    if (transport_ == "MPI") ierr = hymls_mi_set_comm_mpi(h_, mc->Comm(), px, py, pz, &mpi_transport_);
+    else if (transport_ == "RCCL") ierr = hymls_mi_set_comm_rccl_mpi(h_, mc->Comm(), device_, px, py, pz, &nccl_comm_);
+    else return fail(-2, "\"MI Transport\" has to be \"RCCL\" or \"MPI\"");
+    return keep_error(ierr);
+#else
+    return fail(-99, "distributed Epetra maps need the adapter compiled with -DHYMLS_MI_HAVE_MPI");
+#endif
+  }
+  void Release() {
+    if (!h_) return;
+#ifdef HYMLS_MI_HAVE_MPI
+    if (mpi_transport_) { hymls_mi_mpi_transport_free(mpi_transport_); mpi_transport_ = 0; }   // (frees device arenas through h_)
+#endif
+    hymls_mi_destroy(h_);
+    h_ = 0;
+#ifdef HYMLS_MI_HAVE_MPI
+    if (nccl_comm_) { hymls_mi_rccl_comm_destroy(nccl_comm_); nccl_comm_ = 0; }
+#endif
+    overlapMap_ = Teuchos::null; ownedMap_ = Teuchos::null; rowImporter_ = Teuchos::null; vecImporter_ = Teuchos::null;
+  }
   int keep_error(int ierr) const { if (ierr && h_) error_ = hymls_mi_last_error(h_); return ierr; }
   int fail(int code, const char* msg) const { error_ = msg; return code; }
 
@@ -263,7 +403,14 @@ class Preconditioner : public Ifpack_Preconditioner {
   hymls_mi_params p_;
   hymls_mi_t* h_ = 0;
   int device_;
-  bool have_params_ = false, have_border_ = false, matrix_dirty_ = true;
+  bool have_params_ = false, have_border_ = false, matrix_dirty_ = true, distributed_ = false;
+  std::string transport_ = "RCCL";
+  Teuchos::RCP<Epetra_Map> overlapMap_, ownedMap_;            // required rows / owned rows of this rank
+  Teuchos::RCP<Epetra_Import> rowImporter_, vecImporter_;     // matrix row map -> overlapMap_ / ownedMap_
+#ifdef HYMLS_MI_HAVE_MPI
+  hymls_mi_mpi_transport* mpi_transport_ = 0;
+  void* nccl_comm_ = 0;
+#endif
   std::string label_;
   mutable std::string error_;
 };

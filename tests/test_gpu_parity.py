@@ -238,7 +238,7 @@ def test_darcy3d_saddle_point_gpu(gpu_lib):
     assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-8
 
 
-def full_size_properties(gpu_lib, problem, n, levels, re=0.0, max_its=400, sizes=None, sx=8):
+def full_size_properties(gpu_lib, problem, n, levels, re=0.0, max_its=400, sizes=None, sx=8, keep=False, restart=None):
     """Size-independent properties at a BASELINE size the oracle cannot reach: the operator is linear, reproducible
     bit for bit, maps pressure-free right-hand sides to divergence-free velocities (reference
     integration_tests.cpp:453-484, 1e-8), and right-preconditioned GMRES on the device (BaseSolver semantics,
@@ -268,12 +268,16 @@ def full_size_properties(gpu_lib, problem, n, levels, re=0.0, max_its=400, sizes
     # (not a contraction: ||b - K P b|| >> ||b|| for right-hand sides with a divergence part also with the oracle)
     x_ex = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
     rhs = P.MatVec(x_ex).clone()
-    S = hymls_amd.Solver(P, P, {"Krylov Method": "GMRES", "Iterative Solver": {"Convergence Tolerance": 1e-8, "Maximum Iterations": max_its, "Num Blocks": max_its}})
+    S = hymls_amd.Solver(P, P, {"Krylov Method": "GMRES", "Iterative Solver": {"Convergence Tolerance": 1e-8, "Maximum Iterations": max_its, "Num Blocks": restart or max_its,
+                                                                               "Maximum Restarts": 40}})   # (restart: the Krylov basis of 67 M-vectors is 0.5 GB per block)
     xs = S.ApplyInverse(rhs)
     its = S.getNumIter()
+    del S
     true_rel = float((rhs - P.MatVec(xs)).norm() / rhs.norm())
     print("GMRES(%s %d^3 re=%g, Number of Levels=%d): %d iterations, true relative residual %.2e" % (problem, n, re, levels, its, true_rel))
     assert its < max_its and true_rel < 1e-7
+    if keep:
+        return its, P, b1, x1
     return its
 
 
@@ -305,8 +309,57 @@ def test_values_against_the_compiled_cpu_oracle(gpu_lib, kind, n, levels, re):
 
 @pytest.mark.gpu
 def test_full_size_properties_128(gpu_lib):
-    """BASELINE configs[1]/[2] family: Stokes3D 128^3, 3-level, Skew, sx = 8 (8.4 M DoF)"""
+    """BASELINE configs[1]/[2] family: Stokes3D 128^3, 3-level, Skew, sx = 8 (8.4 M DoF).  configs[1] itself (128^3,
+    TWO-level) is covered in value by test_values_against_the_compiled_cpu_oracle at 48^3 and at its size -- incl. its
+    216 k-unknown last-level direct solve -- by test_full_size_cavity_re1000_128 (2-level) and below."""
     full_size_properties(gpu_lib, "Stokes", 128, 2, sizes=[8388608, 216096, 468])
+    full_size_properties(gpu_lib, "Stokes", 128, 1, sizes=[8388608, 216096])          # configs[1] as written
+
+
+@pytest.mark.gpu
+def test_full_size_properties_256_stokes_and_forced_sharded_rccl(gpu_lib, monkeypatch):
+    """BASELINE configs[2] at its size on one MI355X: Stokes3D 256^3 (67 108 864 DoF), 3-level, Skew Cartesian, sx = 8 --
+    the workload of bench.py's default line.  (a) the size-independent properties (linear, bit-reproducible, divergence-
+    free to 1e-8, device GMRES to 1e-8; reference integration_tests.cpp:453-484,486-677), level sizes asserted;
+    (b) the SAME problem through the sharded code path on the library's built-in RCCL transport (one rank that is forced
+    to shard exchanges every halo / hand-off segment with itself through ncclSend/ncclRecv groups and the self-copy):
+    ApplyInverse equals the unsharded one to 1e-10.  N > 1 ranks need N GPUs (the driver's scaling run)."""
+    import torch
+    import hymls_amd
+    from hymls_amd.dist import RcclComm
+    n = 256
+    its, P0, b, x0 = full_size_properties(gpu_lib, "Stokes", n, 2, sizes=[67108864, 1716288, 3528], keep=True, restart=100, max_its=600)
+    assert its <= 300
+    x0 = x0.clone()
+    del P0
+    torch.cuda.empty_cache()      # (the Krylov basis of the GMRES run: 54 GB in torch's cache)
+    monkeypatch.setenv("HYMLS_MI_FORCE_SHARDED", "1")
+    comm = RcclComm(0, lib=gpu_lib)
+    prm = xml_params("Stokes-C", n, 8, 2, partitioner="Skew Cartesian")
+    P = hymls_amd.Preconditioner(None, prm, lib=gpu_lib, comm=comm, rank_grid=(1, 1, 1))
+    assert P.CommSelfTest() == 0
+    req = P.RequiredRows()
+    rows = hymls_amd.generate_problem("Stokes", n, n, n, gids=req, lib=gpu_lib)
+    P.SetMatrixRows(req, rows)
+    P.SetTestVector(hymls_amd.generate_testvector_rows(req, *rows))
+    del rows
+    P.Compute()
+    assert [s[1] for s in P.level_sizes()] == [67108864, 1716288, 3528]
+    owned = torch.from_numpy(P.OwnedRows().astype(np.int64)).cuda()
+    assert owned.numel() == 4 * n ** 3 and int(torch.unique(owned).numel()) == owned.numel()
+    xs = P.ApplyInverse(b[owned].contiguous())
+    torch.cuda.synchronize()
+    err = float((xs - x0[owned]).norm() / x0.norm())
+    print("256^3 forced-sharded (built-in RCCL transport) vs unsharded: relative difference %.2e" % err)
+    assert err < 1e-10
+    del P
+    comm.close()
+
+
+@pytest.mark.gpu
+def test_full_size_properties_256_darcy(gpu_lib):
+    """BASELINE configs[4] at its size on one MI355X: GaleriExt Darcy3D 256^3 (a = 1, b = -1), 3-level"""
+    full_size_properties(gpu_lib, "Darcy", 256, 2, sizes=[67108864, 1716288, 3528], restart=100, max_its=600)
 
 
 @pytest.mark.gpu
@@ -319,8 +372,8 @@ def test_full_size_cavity_re1000_128(gpu_lib):
 
 @pytest.mark.gpu
 def test_full_size_darcy_128(gpu_lib):
-    """BASELINE configs[4] (GaleriExt Darcy3D, a = 1, b = -1) at the largest size one quarter of the 4-GPU run holds
-    comfortably inside a test: 128^3 on one MI355X (bench.py --problem darcy --grid 256 runs the 256^3 problem)."""
+    """BASELINE configs[4] family (GaleriExt Darcy3D, a = 1, b = -1) at 128^3 = one eighth of the 256^3 problem
+    (test_full_size_properties_256_darcy runs that one)."""
     full_size_properties(gpu_lib, "Darcy", 128, 2, sizes=[8388608, 216096, 468])
 
 
@@ -601,3 +654,26 @@ def test_two_pass_separator_transform_fallback_gpu(gpu_lib, tmp_path):
     env = dict(os.environ, HYMLS_MI_SBLOCK_TWO_PASS="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,sx,part", [("Laplace", 16, 4, "Cartesian"), ("Stokes-C", 16, 4, "Cartesian"), ("Stokes-C", 16, 8, "Cartesian"),
+                                          ("Stokes-C", 16, 8, "Skew Cartesian"), ("Stokes-C", 12, 2, "Skew Cartesian")])
+def test_partition_matches_oracle_gpu(gpu_lib, eq, n, sx, part):
+    """the groups the PRODUCT library (libhymls_mi.so, not the host simulator build of the same sources) hands out
+    through hymls_mi_get_interior / hymls_mi_get_separator_groups == the oracle's restatement of
+    CartesianPartitioner::GetGroups / SkewCartesianPartitioner + HierarchicalMap ownership, bit for bit"""
+    import hymls_amd
+    from oracle.partition import Params, HierarchicalMap
+    A, tv = problem(eq, n)
+    P = hymls_amd.Preconditioner(A, xml_params(eq, n, sx, 0, partitioner=part), testVector=tv, lib=gpu_lib)
+    P.Initialize()
+    hm = HierarchicalMap(Params(nx=n, ny=n, nz=n, sx=sx, levels=0, equations=eq, partitioner=part).finalize())
+    assert P.level_sizes()[0][3] == hm.nsd
+    for sd in range(hm.nsd):
+        assert np.array_equal(P.interior(0, sd), hm.interior[sd])
+        groups = P.separator_groups(0, sd)
+        assert len(groups) == len(hm.groups[sd])
+        for gi, (typ, owned, nodes) in enumerate(groups):
+            assert typ == hm.groups[sd][gi][0] and np.array_equal(nodes, hm.groups[sd][gi][1])
+            assert owned == (gi in hm.owned[sd])

@@ -114,6 +114,8 @@ def load_library(path=None):
                                                C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I32P, _I32P, _F64P]),
         "hymls_mi_generate_problem": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64,
                                                 _I32P, _I64P, _I32P, _I32P, _F64P]),
+        "hymls_mi_generate_problem_periodic": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                                         C.c_int64, _I32P, _I64P, _I32P, _I32P, _F64P]),
         "hymls_mi_generate_testvector": (C.c_int, [C.c_int64, _I32P, _I32P, _F64P, _F64P]),
         "hymls_mi_drop_by_value": (C.c_int, [C.c_int64, _I32P, _I32P, _F64P, C.c_double, C.c_int, _I64P, _I32P, _I32P, _F64P]),
         "hymls_mi_last_error": (C.c_char_p, [H]),
@@ -177,7 +179,7 @@ def generate_rows(equations, nx, ny, nz, gids, a=None, b=1.0, lib=None):
 _PROBLEM = {"Laplace": 0, "Stokes-C": 1, "Stokes": 1, "Darcy": 2, "Oseen": 3, "Cavity": 3}
 
 
-def generate_problem(problem, nx, ny, nz, a=None, b=None, re=0.0, gids=None, lib=None):
+def generate_problem(problem, nx, ny, nz, a=None, b=None, re=0.0, gids=None, lib=None, periodic=(False, False, False)):
     """CSR arrays (rowptr, global colind, val) of a BASELINE input (include/hymls_mi.h: hymls_mi_generate_problem):
     'Laplace', 'Stokes' (a = nx^2, b = 1), 'Darcy' (a = 1, b = -1, reference src/HYMLS_MainUtils.cpp:300-306),
     'Cavity' (Stokes + convection at Reynolds number `re`).  gids: only these rows (sharded runs)."""
@@ -193,13 +195,14 @@ def generate_problem(problem, nx, ny, nz, a=None, b=None, re=0.0, gids=None, lib
         gids = np.ascontiguousarray(gids, dtype=np.int32)
         n, gp = gids.size, _i32(gids)
     nnz = C.c_int64()
-    ierr = lib.hymls_mi_generate_problem(kind, nx, ny, nz, a, b, re, n, gp, C.byref(nnz), None, None, None)
+    per = sum((4 >> d) for d in range(3) if periodic[d])       # GaleriExt::PERIO_Flag bits
+    ierr = lib.hymls_mi_generate_problem_periodic(kind, nx, ny, nz, a, b, re, per, n, gp, C.byref(nnz), None, None, None)
     if ierr:
         raise HymlsError(ierr, "generate_problem")
     rowptr = np.empty(n + 1, np.int32)
     col = np.empty(max(nnz.value, 1), np.int32)
     val = np.empty(max(nnz.value, 1), np.float64)
-    lib.hymls_mi_generate_problem(kind, nx, ny, nz, a, b, re, n, gp, C.byref(nnz), _i32(rowptr), _i32(col), _f64(val))
+    lib.hymls_mi_generate_problem_periodic(kind, nx, ny, nz, a, b, re, per, n, gp, C.byref(nnz), _i32(rowptr), _i32(col), _f64(val))
     return rowptr, col[:nnz.value], val[:nnz.value]
 
 
@@ -360,9 +363,10 @@ class Preconditioner:
             p.retain_at_level[l] = prec.get("Retain Nodes at Level %d" % l, -1)
             for d, ax in enumerate("xyz"):
                 p.retain_at_level_xyz[l][d] = prec.get("Retain Nodes at Level %d (%s)" % (l, ax), -1)
-        perio = int(prob.get("Periodicity", sum((1 << d) for d, ax in enumerate("xyz") if prob.get("%s-periodic" % ax, False))))
+        # GaleriExt::PERIO_Flag bits: X 4, Y 2, Z 1 (reference src/GaleriExt_Periodic.h)
+        perio = int(prob.get("Periodicity", sum((4 >> d) for d, ax in enumerate("xyz") if prob.get("%s-periodic" % ax, False))))
         for d in range(3):
-            p.periodic[d] = (perio >> d) & 1
+            p.periodic[d] = (perio >> (2 - d)) & 1
         p.retain_pressures = prob.get("Retained Pressure Nodes", -1)
         p.link_velocities = int(prec.get("Eliminate Velocities Together", True))
         p.link_retained = int(prec.get("Eliminate Retained Nodes Together", True))

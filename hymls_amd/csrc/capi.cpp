@@ -8,7 +8,7 @@ namespace hymls {
 int64_t generate_laplace3d(int nx, int ny, int nz, int32_t* rowptr, int32_t* col, double* val);
 int64_t generate_stokes3d(int nx, int ny, int nz, double a, double b, int32_t* rowptr, int32_t* col, double* val);
 int64_t generate_rows(int equations, int nx, int ny, int nz, double a, double b, int64_t nrows, const int32_t* gids,
-                      int32_t* rowptr, int32_t* col, double* val, double re);
+                      int32_t* rowptr, int32_t* col, double* val, double re, const bool* per);
 }
 
 using namespace hymls;
@@ -583,20 +583,27 @@ int hymls_mi_generate_matrix(int equations, int nx, int ny, int nz, double a, do
 int hymls_mi_generate_rows(int equations, int nx, int ny, int nz, double a, double b, int64_t nrows, const int32_t* gids,
                            int64_t* nnz, int32_t* rowptr, int32_t* colgid, double* val) {
   if (!nnz || !gids || (equations != 0 && equations != 1)) return -2;
-  try { *nnz = generate_rows(equations, nx, ny, nz, a, b, nrows, gids, rowptr, colgid, val, 0.0); }
+  try { *nnz = generate_rows(equations, nx, ny, nz, a, b, nrows, gids, rowptr, colgid, val, 0.0, nullptr); }
+  catch (...) { return -2; }
+  return 0;
+}
+
+int hymls_mi_generate_problem_periodic(int problem, int nx, int ny, int nz, double a, double b, double re, int periodicity,
+                                       int64_t nrows, const int32_t* gids, int64_t* nnz, int32_t* rowptr, int32_t* colgid, double* val) {
+  if (!nnz || problem < 0 || problem > 3 || nx <= 0 || ny <= 0 || nz <= 0 || periodicity < 0 || periodicity > 7) return -2;
+  const int64_t N = (int64_t)nx * ny * nz * (problem == 0 ? 1 : 4);
+  if (!gids && nrows != N) return -2;
+  if (gids) for (int64_t t = 0; t < nrows; t++) if (gids[t] < 0 || gids[t] >= N) return -2;
+  const bool per[3] = {(periodicity & 4) != 0, (periodicity & 2) != 0, (periodicity & 1) != 0};   // GaleriExt::PERIO_Flag: X 4, Y 2, Z 1
+  try { *nnz = generate_rows(problem, nx, ny, nz, a, b, nrows, gids, rowptr, colgid, val, re, per); }
+  catch (const hymls::Error& e) { return e.code; }
   catch (...) { return -2; }
   return 0;
 }
 
 int hymls_mi_generate_problem(int problem, int nx, int ny, int nz, double a, double b, double re, int64_t nrows,
                               const int32_t* gids, int64_t* nnz, int32_t* rowptr, int32_t* colgid, double* val) {
-  if (!nnz || problem < 0 || problem > 3 || nx <= 0 || ny <= 0 || nz <= 0) return -2;
-  const int64_t N = (int64_t)nx * ny * nz * (problem == 0 ? 1 : 4);
-  if (!gids && nrows != N) return -2;
-  if (gids) for (int64_t t = 0; t < nrows; t++) if (gids[t] < 0 || gids[t] >= N) return -2;
-  try { *nnz = generate_rows(problem, nx, ny, nz, a, b, nrows, gids, rowptr, colgid, val, re); }
-  catch (...) { return -2; }
-  return 0;
+  return hymls_mi_generate_problem_periodic(problem, nx, ny, nz, a, b, re, 0, nrows, gids, nnz, rowptr, colgid, val);
 }
 
 int hymls_mi_generate_testvector(int64_t n, const int32_t* rowptr, const int32_t* colind, const double* val, double* tv) {

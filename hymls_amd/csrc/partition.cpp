@@ -12,9 +12,10 @@ struct Range {
 
 // one coordinate direction of a subdomain is cut into three pieces: the layer in
 // front of it (type 0), its own cells (type 1) and its closing separator layer
-// (type 2).  Behaviour of GetSubdomainStartAndEnd (CartesianPartitioner.cpp:224-263)
-// for non-periodic grids, including "Retain Nodes" > 1 (idx_max pieces of type 1).
-Range piece(int pos, int idx, int idx_max, int dim, int mx) {
+// (type 2).  Behaviour of GetSubdomainStartAndEnd (CartesianPartitioner.cpp:224-263),
+// including "Retain Nodes" > 1 (idx_max pieces of type 1); in a periodic direction the first
+// subdomain keeps its front layer and the last one its closing layer (they wrap around).
+Range piece(int pos, int idx, int idx_max, int dim, int mx, bool perio) {
   Range r{false, 0, 0, 0};
   const int len = std::max((mx + idx_max - 1) / idx_max, 1);
   r.type = (idx == idx_max) ? 2 : (idx >= 0 ? 1 : 0);
@@ -23,10 +24,12 @@ Range piece(int pos, int idx, int idx_max, int dim, int mx) {
   else if (idx > 0) r.start = std::min(len * idx, mx);
   r.end = r.start + 1;
   if (r.type == 1) r.end = std::min(len * (idx + 1), mx);
-  if (pos == 0 && idx == -1) { r.skip = true; return r; }
-  if (pos + mx + 1 == dim) {
-    if (idx == idx_max) { r.skip = true; return r; }
-    if (idx == idx_max - 1) r.end += 1;
+  if (!perio) {
+    if (pos == 0 && idx == -1) { r.skip = true; return r; }
+    if (pos + mx + 1 == dim) {
+      if (idx == idx_max) { r.skip = true; return r; }
+      if (idx == idx_max - 1) r.end += 1;
+    }
   }
   if (r.start == r.end) r.skip = true;
   return r;
@@ -53,15 +56,15 @@ void cartesian_get_groups(const Params& p, int sd, ivec& interior, std::vector<G
   ivec retained;
   for (int kidx = -1; kidx <= kmax; kidx++) {
     const bool kint = kidx >= 0 && kidx < kmax;
-    Range K = piece(zpos, kidx, kmax, p.nz, zmax);
+    Range K = piece(zpos, kidx, kmax, p.nz, zmax, p.perio[2]);
     if (K.skip) continue;
     for (int jidx = -1; jidx <= jmax; jidx++) {
       const bool jint = jidx >= 0 && jidx < jmax;
-      Range J = piece(ypos, jidx, jmax, p.ny, ymax);
+      Range J = piece(ypos, jidx, jmax, p.ny, ymax, p.perio[1]);
       if (J.skip) continue;
       for (int iidx = -1; iidx <= imax; iidx++) {
         const bool iint = iidx >= 0 && iidx < imax;
-        Range I = piece(xpos, iidx, imax, p.nx, xmax);
+        Range I = piece(xpos, iidx, imax, p.nx, xmax, p.perio[0]);
         if (I.skip) continue;
         for (int d = 0; d < p.dof; d++) {
           const int32_t vt = p.vtype[d];

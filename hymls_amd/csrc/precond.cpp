@@ -367,21 +367,28 @@ Csr DirectSolver::prepare(const Csr& A0, const ivec& gids, const ivec& fix_gids,
       }
     fix_rows.push_back(lid);
   }
-  tail_z_ = -1;
+  tail_z_.clear();
   if (border_pending && fix_gids.empty() && n > 0) {
     // the last pressure node (if the problem has pressures) joins the border: its row and column are kept aside and
-    // replaced by a Dirichlet row in the matrix that is factored
-    int z = -1;
-    for (int i = n - 1; i >= 0 && z < 0; i--) if (cp.vtype[gids[i] % cp.dof] == VT_P) z = i;
-    if (z >= 0) {
-      tail_z_ = z;
-      tail_col_.assign(n, 0.0); tail_row_.assign(n, 0.0);
+    // replaced by a Dirichlet row in the matrix that is factored.  On a grid with periodic directions the constant of
+    // every velocity component can be a null vector as well (the reference's periodic Stokes3D has Neumann velocity
+    // Laplacians, GaleriExt_Stokes3D.h:77-80; its driver borders with the dof constants, "Null Space Type" = "Constant",
+    // HYMLS_MainUtils.cpp:361-376): the last node of each velocity component joins the border too.
+    auto last_of = [&](int32_t vt) { for (int i = n - 1; i >= 0; i--) if (cp.vtype[gids[i] % cp.dof] == vt) return i; return -1; };
+    std::vector<int32_t> kinds = {VT_P};
+    if (cp.perio[0] || cp.perio[1] || cp.perio[2]) for (int32_t vt : {VT_U, VT_V, VT_W, VT_LAPLACE}) kinds.push_back(vt);
+    for (int32_t vt : kinds) { const int z = last_of(vt); if (z >= 0) tail_z_.push_back(z); }
+    const int tl = (int)tail_z_.size();
+    if (tl) {
+      ivec pos(n, -1);
+      for (int t = 0; t < tl; t++) pos[tail_z_[t]] = t;
+      tail_col_.assign((size_t)n * tl, 0.0); tail_row_.assign((size_t)n * tl, 0.0); tail_d_.assign((size_t)tl * tl, 0.0);
       for (int i = 0; i < n; i++)
         for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++) {
-          const int c = A.col[e];
-          if (i == z && c == z) { tail_d_ = A.val[e]; A.val[e] = 1.0; }
-          else if (i == z) { tail_row_[c] = A.val[e]; A.val[e] = 0.0; }
-          else if (c == z) { tail_col_[i] = A.val[e]; A.val[e] = 0.0; }
+          const int c = A.col[e], ti = pos[i], tc = pos[c];
+          if (ti >= 0 && tc >= 0) { tail_d_[ti + (size_t)tl * tc] = A.val[e]; A.val[e] = (i == c) ? 1.0 : 0.0; }
+          else if (ti >= 0) { tail_row_[c + (size_t)n * ti] = A.val[e]; A.val[e] = 0.0; }
+          else if (tc >= 0) { tail_col_[i + (size_t)n * tc] = A.val[e]; A.val[e] = 0.0; }
         }
     }
   }
@@ -472,7 +479,7 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
 // reference's CoarseSolver keeps its Amesos solver across Compute calls in the same way, CoarseSolver.cpp:131-152.)
 bool DirectSolver::refactor(const Csr& A0, const ivec& gids, const ivec& fix_gids, const Params& cp, bool border_pending) {
   if (n_ == 0 || !lu_ || border_pending != border_pending_ || gids != pat_gids_ || fix_gids != pat_fix_) return false;
-  const int32_t tail_before = tail_z_;
+  const ivec tail_before = tail_z_;
   ivec fix_rows;
   Csr A = prepare(A0, gids, fix_gids, cp, border_pending, fix_rows);
   if (A.n != n_ || tail_z_ != tail_before || A.rowptr != pat_rowptr_ || A.col != pat_col_ || zero_diagonal(A) != pat_zero_diag_) return false;
@@ -520,31 +527,30 @@ void DirectSolver::set_border(int m, const double* dV, const double* dW, const d
   bm_ = 0; bMinv_.clear();
   if (m <= 0 || n_ == 0) return;
   bm_ = m;
-  const int tl = tail_z_ >= 0 ? 1 : 0, mt = m + tl;
+  const int tl = (int)tail_z_.size(), mt = m + tl;
   const size_t n = (size_t)n_;
-  // border columns [tail column | V], border rows [tail row | W]; entries at the tail node go to the small block D
+  // border columns [tail columns | V], border rows [tail rows | W]; entries at the tail nodes go to the small block D
   dvec D((size_t)mt * mt, 0.0);
   d_bZ_ = (double*)dev::alloc(n * mt * sizeof(double));
   d_bW_ = (double*)dev::alloc(n * mt * sizeof(double));
   double* d_U = (double*)dev::alloc(n * mt * sizeof(double));
   if (tl) {
-    dev::h2d(d_U, tail_col_.data(), n * sizeof(double));
-    dev::h2d(d_bW_, tail_row_.data(), n * sizeof(double));
-    D[0] = tail_d_;
+    dev::h2d(d_U, tail_col_.data(), n * tl * sizeof(double));
+    dev::h2d(d_bW_, tail_row_.data(), n * tl * sizeof(double));
+    for (int j = 0; j < tl; j++) for (int i = 0; i < tl; i++) D[i + (size_t)mt * j] = tail_d_[i + (size_t)tl * j];
   }
   dev::d2d(d_U + n * tl, dV, n * m * sizeof(double));
   dev::d2d(d_bW_ + n * tl, dW, n * m * sizeof(double));
   for (int j = 0; j < m; j++)
     for (int i = 0; i < m; i++) D[(i + tl) + (size_t)mt * (j + tl)] = C[i + (size_t)m * j];
-  if (tl) {
-    const double zero = 0.0;
+  const double zero = 0.0;
+  for (int t = 0; t < tl; t++)
     for (int j = 0; j < m; j++) {
-      dev::d2h(&D[0 + (size_t)mt * (j + 1)], d_U + n * (j + 1) + tail_z_, sizeof(double));      // V[z, j]
-      dev::d2h(&D[(j + 1) + (size_t)mt * 0], d_bW_ + n * (j + 1) + tail_z_, sizeof(double));    // W[z, j]
-      dev::h2d(d_U + n * (j + 1) + tail_z_, &zero, sizeof(double));
-      dev::h2d(d_bW_ + n * (j + 1) + tail_z_, &zero, sizeof(double));
+      dev::d2h(&D[t + (size_t)mt * (j + tl)], d_U + n * (j + tl) + tail_z_[t], sizeof(double));      // V[z_t, j]
+      dev::d2h(&D[(j + tl) + (size_t)mt * t], d_bW_ + n * (j + tl) + tail_z_[t], sizeof(double));    // W[z_t, j]
+      dev::h2d(d_U + n * (j + tl) + tail_z_[t], &zero, sizeof(double));
+      dev::h2d(d_bW_ + n * (j + tl) + tail_z_[t], &zero, sizeof(double));
     }
-  }
   for (int j = 0; j < mt; j++) solve(d_U + n * j, d_bZ_ + n * j, false);                  // Z = A^{-1} U
   dev::free(d_U);
   // M = D - W' Z, inverted on the host with partial pivoting
@@ -571,15 +577,14 @@ void DirectSolver::set_border(int m, const double* dV, const double* dW, const d
 
 void DirectSolver::apply_inverse_bordered(const double* b, const double* T, double* x, double* S) {
   if (bm_ == 0) { apply_inverse(b, x); return; }
-  const int tl = tail_z_ >= 0 ? 1 : 0, mt = bm_ + tl;
+  const int tl = (int)tail_z_.size(), mt = bm_ + tl;
   const size_t n = (size_t)n_;
   dvec r(mt), y(mt);
   if (tl) {
-    // the equation of the tail node belongs to the border: its right-hand side entry moves there
-    dev::d2h(&r[0], b + tail_z_, sizeof(double));
+    // the equations of the tail nodes belong to the border: their right-hand side entries move there
     dev::d2d(x, b, n * sizeof(double));          // (x doubles as the modified right-hand side)
     const double zero = 0.0;
-    dev::h2d(x + tail_z_, &zero, sizeof(double));
+    for (int t = 0; t < tl; t++) { dev::d2h(&r[t], b + tail_z_[t], sizeof(double)); dev::h2d(x + tail_z_[t], &zero, sizeof(double)); }
     solve(x, x, false);
   } else {
     solve(b, x, false);                           // (the augmented system of the reference does not zero the fixed rows)
@@ -588,7 +593,7 @@ void DirectSolver::apply_inverse_bordered(const double* b, const double* T, doub
   for (int i = 0; i < mt; i++) r[i] -= dev::dot(n_, d_bW_ + n * i, x);
   for (int i = 0; i < mt; i++) { y[i] = 0.0; for (int j = 0; j < mt; j++) y[i] += bMinv_[i + (size_t)mt * j] * r[j]; }
   for (int j = 0; j < mt; j++) dev::axpby(n_, -y[j], d_bZ_ + n * j, 1.0, x);
-  if (tl) dev::h2d(x + tail_z_, &y[0], sizeof(double));
+  for (int t = 0; t < tl; t++) dev::h2d(x + tail_z_[t], &y[t], sizeof(double));
   for (int i = 0; i < bm_; i++) S[i] = y[i + tl];
 }
 
@@ -683,6 +688,8 @@ void LevelSolver::partition(const ivec* level_gids) {
   if (level_gids) { present.assign(ngid_, 0); for (int32_t g : *level_gids) present[g] = 1; }
   sd_rank_.assign(nsd, 0);
   std::vector<char> cand;
+  HYMLS_CHECK(!(dist && (p_.perio[0] || p_.perio[1] || p_.perio[2])), -99,
+              "periodic grids are not implemented for sharded handles (the halo of a rank's box does not wrap around)");
   if (dist) {
     cand.assign(nsd, 0);
     const int bx = (p_.nx + comm_->px - 1) / comm_->px, by = (p_.ny + comm_->py - 1) / comm_->py,
@@ -1016,9 +1023,20 @@ void LevelSolver::build_classes() {
     // relative coordinates
     lp.coord.resize(3 * (size_t)lp.nI);
     int32_t mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
+    int spos[3] = {0, 0, 0};
+    const bool wraps = p_.perio[0] || p_.perio[1] || p_.perio[2];
+    if (wraps) sd_position(p_, s, spos[0], spos[1], spos[2]);
+    const int nn[3] = {p_.nx, p_.ny, p_.nz}, ss[3] = {p_.sx, p_.sy, p_.sz};
     for (int i = 0; i < lp.nI; i++) {
-      gid_coord(p_, S.interior[i], &lp.coord[3 * (size_t)i]);
-      for (int a = 0; a < 3; a++) mn[a] = std::min(mn[a], lp.coord[3 * (size_t)i + a]);
+      int32_t* cc = &lp.coord[3 * (size_t)i];
+      gid_coord(p_, S.interior[i], cc);
+      // a subdomain that reaches across a periodic boundary: the image next to the subdomain's reference corner (every
+      // node lies within [pos - s - 1, pos + s + 1]), so that relative coordinates are those of an inner subdomain
+      if (wraps) for (int a = 0; a < 3; a++) if (p_.perio[a]) {
+        const int lo = 2 * (spos[a] - ss[a] - 1), per2 = 2 * nn[a];
+        cc[a] = lo + (((cc[a] - lo) % per2) + per2) % per2;
+      }
+      for (int a = 0; a < 3; a++) mn[a] = std::min(mn[a], cc[a]);
     }
     for (int i = 0; i < lp.nI; i++) for (int a = 0; a < 3; a++) lp.coord[3 * (size_t)i + a] -= mn[a] & ~1;
     Hasher H;

@@ -123,10 +123,9 @@ class DirectSolver : public Operator {
   int bm_ = 0;
   double *d_bZ_ = nullptr, *d_bW_ = nullptr;
   dvec bMinv_;
-  // tail: row/column tail_z_ of the matrix lives in the border (see the constructor)
-  int32_t tail_z_ = -1;
-  dvec tail_col_, tail_row_;
-  double tail_d_ = 0.0;
+  // tail: the rows/columns tail_z_ of the matrix live in the border (see prepare): n x tl columns / rows, tl x tl block
+  ivec tail_z_;
+  dvec tail_col_, tail_row_, tail_d_;
   std::unique_ptr<BatchedLU> lu_;
   MergedSolve merged_;
   dev::PlanD* d_plan_ = nullptr;

@@ -1,7 +1,8 @@
 // skew.cpp -- "Skew Cartesian" partitioner: subdomains are xy-diamonds that shear with z, so that
 // no pressure node is left isolated on a subdomain edge (needed for 3D Stokes on a C grid).
 //
-// Behaviour of the reference's SkewCartesianPartitioner for non-periodic grids and
+// Behaviour of the reference's SkewCartesianPartitioner, periodic directions included (:154-159 duplicate
+// subdomains, :199-206 ids across the periodic boundary, :686-688 wrap-around), for
 // "Retain Nodes" <= 1 (src/HYMLS_SkewCartesianPartitioner.cpp: subdomain numbering :128-213,
 // node template :349-563, grouping by the set of neighbouring subdomains :565-651, placement,
 // clipping, retained pressure, ownership split and wall nodes :653-812).  Here the template is
@@ -178,6 +179,10 @@ inline int skew_owner(const Params& p, int x, int y, int z) {
   if (!front) sd += dir1;
   if (!right) sd += dir2;
   if (!below) sd += dir3;
+  // across a periodic boundary the subdomain is the one at the other end (reference :199-206)
+  if (!front && right && p.perio[0] && xc == npx - 1) sd -= dir2;
+  if (!front && !right && p.perio[1] && yc == npy - 1) sd -= dir3 - dir2;
+  if (!below && p.perio[2] && zc == p.nz / p.sz - 1) sd -= (p.nz / p.sz) * dir3;
   return sd;
 }
 
@@ -213,11 +218,17 @@ void skew_get_groups(const Params& p, int sd, ivec& interior, std::vector<Group>
   const int sx = p.sx, dof = p.dof;
   int sdx, sdy, sdz;
   skew_position(p, sd, sdx, sdy, sdz);
+  // the periodic image of another subdomain (GetSubdomainPosition returns 1 and CreateSubdomainMap leaves it out,
+  // reference :154-159,249-250): it stays in the numbering as an empty subdomain
+  if ((sdx == p.nx - sx / 2 && p.perio[0]) || (sdy == p.ny && p.perio[1]) || (sdz == p.nz && p.perio[2])) return;
   // place the template: the auxiliary origin sits at (sdx - 1, sdy - 1 - sx/2, sdz - sx) after
   // removing the (sx, sx, sx) shift the reference applies before grouping (:585, :683-685)
   const int ox = sdx - 1, oy = sdy - 1 - sx / 2, oz = sdz - sx;
   auto place = [&](const Pt& q, int32_t& gid, int& x, int& y, int& z) {
     x = q.x + ox; y = q.y + oy; z = q.z + oz;
+    if (p.perio[0]) x = (x + p.nx) % p.nx;
+    if (p.perio[1]) y = (y + p.ny) % p.ny;
+    if (p.perio[2]) z = (z + p.nz) % p.nz;
     if (x < 0 || x >= p.nx || y < 0 || y >= p.ny || z < 0 || z >= p.nz) return false;
     gid = ((z * p.ny + y) * p.nx + x) * dof + q.var;
     return true;
@@ -268,8 +279,8 @@ void skew_get_groups(const Params& p, int sd, ivec& interior, std::vector<Group>
       const int var = node % dof, c = node / dof;
       const int x = c % p.nx, y = (c / p.nx) % p.ny, z = c / (p.nx * p.ny);
       const int32_t vt = p.vtype[var];
-      const bool wall = dof > 1 && ((x == p.nx - 1 && vt == VT_U) || (y == p.ny - 1 && vt == VT_V) ||
-                                    (p.nz > 1 && z == p.nz - 1 && vt == VT_W));
+      const bool wall = dof > 1 && ((x == p.nx - 1 && vt == VT_U && !p.perio[0]) || (y == p.ny - 1 && vt == VT_V && !p.perio[1]) ||
+                                    (p.nz > 1 && z == p.nz - 1 && vt == VT_W && !p.perio[2]));
       if (!wall) { keep.push_back(node); continue; }
       if (skew_owner(p, x, y, z) == sd) interior.push_back(node);
     }

@@ -106,7 +106,8 @@ class RcclComm:
         self.error = None
 
     def attach(self, prec):
-        self._prec = prec
+        import weakref
+        self._prec = weakref.proxy(prec)      # (no reference cycle: `del P` has to free the handle's device memory at once)
 
     def close(self):
         if self.nccl_comm is not None:
@@ -139,7 +140,8 @@ class TorchComm:
         self.error = None
 
     def attach(self, prec):
-        self._prec = prec
+        import weakref
+        self._prec = weakref.proxy(prec)
 
     # ---- callbacks (no exception may cross the C boundary)
     def _alloc_arena(self, ctx, nbytes):

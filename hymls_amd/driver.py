@@ -12,8 +12,12 @@ hymls_amd.Preconditioner and hymls_amd.Solver, so that the reference's own examp
   "Exact Solution Available",
 * "Problem", "Preconditioner", "Solver" sublists go to the operator classes unchanged.
 * "Null Space Type" = "Constant P" (testSuite/cavity.xml): the constant-pressure vector becomes the border of the
-  system and of the preconditioner (hymls_amd.BorderedSolver), so that "Fix Pressure Level" = false works.
-Not supported: "Null Space Type" = "File", deflation of further vectors, eigenvalue runs.
+  system and of the preconditioner (hymls_amd.BorderedSolver), so that "Fix Pressure Level" = false works;
+  "Constant" (testSuite/integration_tests/stokes4_3D.xml): one constant per degree of freedom, scaled by
+  1 / sqrt(number of cells) (create_nullspace, src/HYMLS_MainUtils.cpp:361-376); the exact solution of a generated
+  right-hand side has the null space projected out (src/main.cpp:401-409).
+* "x-periodic" / "y-periodic" / "z-periodic" of the "Problem" list (generated Stokes-C matrices).
+Not supported: "Null Space Type" = "File" / "Checkerboard", deflation of further vectors, eigenvalue runs.
 """
 import os
 import re
@@ -112,9 +116,12 @@ def run(xml_file, *overlays, lib=None, device=None, out=sys.stdout):
         if drv.get("Exact Solution Available", False):
             sol = read_matrix_market(os.path.join(d, "sol.mtx"))
     else:
-        if dim != 3 or eqn not in ("Laplace", "Stokes-C"):
-            raise ValueError("generated problems: 3D Laplace or Stokes-C")
-        K = hymls_amd.generate_matrix(eqn, nx, ny, nz, lib=lib)
+        label = drv.get("Galeri Label", eqn)            # (main.cpp:131: the label defaults to the "Equations")
+        if dim != 3 or label not in ("Laplace", "Laplace3D", "Stokes-C", "Darcy"):
+            raise ValueError("generated problems: 3D Laplace, Stokes-C or Darcy")
+        per = tuple(bool(prob.get("%s-periodic" % ax, False)) for ax in "xyz")
+        K = hymls_amd.generate_problem({"Laplace": "Laplace", "Laplace3D": "Laplace", "Stokes-C": "Stokes", "Darcy": "Darcy"}[label],
+                                       nx, ny, nz, lib=lib, periodic=per)
     n = K[0].size - 1
     rows = np.repeat(np.arange(n), np.diff(K[0]))
     tv = np.zeros(n); tv[np.unique(rows[(K[2] != 0.0) & (K[1] != rows)])] = 1.0     # create_testvector
@@ -124,11 +131,18 @@ def run(xml_file, *overlays, lib=None, device=None, out=sys.stdout):
     P.Initialize()
     res["initialize_s"] = time.time() - t0
     null_space = drv.get("Null Space Type", "None")
+    V = None
     if null_space == "Constant P":
         dof = prob.get("Degrees of Freedom", dim + 1)
-        v = np.zeros((n, 1)); v[dof - 1::dof, 0] = 1.0
+        V = np.zeros((n, 1)); V[dof - 1::dof, 0] = 1.0
+    elif null_space == "Constant":
+        dof = prob.get("Degrees of Freedom", dim + 1 if eqn == "Stokes-C" else 1)
+        V = np.zeros((n, dof))
+        for d in range(dof):
+            V[d::dof, d] = 1.0 / np.sqrt(n // dof)
+    if V is not None:
         S = hymls_amd.BorderedSolver(P, P, params)
-        S.SetBorder(v, device=device)
+        S.SetBorder(V, device=device)
     elif null_space == "None":
         S = hymls_amd.Solver(P, P, params)
     else:
@@ -148,18 +162,26 @@ def run(xml_file, *overlays, lib=None, device=None, out=sys.stdout):
             else:
                 if x_ex is None:
                     x_ex = rng.uniform(-1, 1, n)
+                    if V is not None and null_space == "Constant":      # project the null space out (main.cpp:401-409)
+                        x_ex -= V @ (V.T @ x_ex)
                 b = P.MatVec(torch.from_numpy(np.ascontiguousarray(x_ex)).to(device)).clone()
             t0 = time.time()
             x = S.ApplyInverse(b)
+            sb = None
             if isinstance(x, tuple):        # bordered: (X, S)
-                x = x[0]
+                x, sb = x
             t_solve = time.time() - t0
-            r = float((b - P.MatVec(x)).norm() / b.norm())
+            rvec = b - P.MatVec(x)
+            if sb is not None and len(sb):
+                rvec = rvec - torch.from_numpy(V @ sb).to(rvec.device)
+            r = float(rvec.norm() / b.norm())
             rec = {"iterations": S.getNumIter(), "residual": r, "solve_s": t_solve}
             if x_ex is not None:
                 e = x.cpu().numpy() - x_ex
                 dof = prob.get("Degrees of Freedom", dim + 1 if eqn == "Stokes-C" else 1)
-                if eqn == "Stokes-C":     # the pressure is determined up to a constant: compare the velocities
+                if null_space == "Constant":   # the null space is projected out of x_ex and excluded by the border
+                    rec["error"] = float(np.linalg.norm(e) / np.linalg.norm(x_ex))
+                elif eqn == "Stokes-C":     # the pressure is determined up to a constant: compare the velocities
                     e = e[np.arange(n) % dof != dof - 1]
                     rec["error"] = float(np.linalg.norm(e) / np.linalg.norm(x_ex[np.arange(n) % dof != dof - 1]))
                 else:
@@ -168,6 +190,9 @@ def run(xml_file, *overlays, lib=None, device=None, out=sys.stdout):
             print("solve %d.%d: %d iterations, residual %.3e%s, %.3f s" %
                   (f, s, rec["iterations"], r, ", error %.3e" % rec["error"] if "error" in rec else "", t_solve), file=out)
     res["levels"] = P.level_sizes()
+    if res["solves"]:                      # what the reference's "Targets" list is checked against
+        last = res["solves"][-1]
+        res["iterations"], res["relative_residual"], res["relative_error"] = last["iterations"], last["residual"], last.get("error")
     return res
 
 

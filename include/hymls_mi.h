@@ -57,7 +57,7 @@ typedef struct hymls_mi_params {
   int32_t retain_at_level_xyz[8][3]; /* "Retain Nodes at Level k (x|y|z)" (-1: unset): wins over "Retain Nodes (x|y|z)",
                                    src/HYMLS_BasePartitioner.cpp:112-124 */
   int32_t periodic[3];          /* "x-periodic", "y-periodic", "z-periodic" of the "Problem" list (0|1), or the bits of
-                                   "Periodicity" (GaleriExt::PERIO_Flag: 1 x, 2 y, 4 z), src/HYMLS_BasePartitioner.cpp:49-62 */
+                                   "Periodicity" (GaleriExt::PERIO_Flag: 4 x, 2 y, 1 z), src/HYMLS_BasePartitioner.cpp:49-62 */
 } hymls_mi_params;
 
 /* fill *p with the reference defaults (everything -1 / default flags). */
@@ -239,6 +239,14 @@ int hymls_mi_generate_rows(int equations, int nx, int ny, int nz, double a, doub
  * gids == NULL: all nrows = nx ny nz dof rows; else the listed rows (sharded runs).  rowptr == NULL: count only. */
 int hymls_mi_generate_problem(int problem, int nx, int ny, int nz, double a, double b, double re, int64_t nrows,
                               const int32_t* gids, int64_t* nnz, int32_t* rowptr, int32_t* colgid, double* val);
+/* the same with periodic directions: periodicity = GaleriExt::PERIO_Flag bits (reference src/GaleriExt_Periodic.h:
+ * X_PERIO 4, Y_PERIO 2, Z_PERIO 1; what create_matrix builds from "x-periodic" .., src/HYMLS_MainUtils.cpp:277-285).
+ * Stokes3D and Darcy3D only.  Stokes3D is restated as the reference builds it: gradient / divergence wrap around, the
+ * velocity Laplacians are the Neumann matrices of GaleriExt::Cross3DN without couplings across the periodic boundary
+ * (src/GaleriExt_Stokes3D.h:77-80). */
+int hymls_mi_generate_problem_periodic(int problem, int nx, int ny, int nz, double a, double b, double re, int periodicity,
+                                       int64_t nrows, const int32_t* gids, int64_t* nnz, int32_t* rowptr, int32_t* colgid,
+                                       double* val);
 /* create_testvector (reference src/HYMLS_MainUtils.cpp:208-258). */
 int hymls_mi_generate_testvector(int64_t nrows, const int32_t* rowptr, const int32_t* colind,
                                  const double* val, double* tv);

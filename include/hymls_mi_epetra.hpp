@@ -108,10 +108,11 @@ class Preconditioner : public Ifpack_Preconditioner {
     // read from the "Problem" list, as the reference does (src/HYMLS_BasePartitioner.cpp:224,244,263)
     p_.retain_pressures = prob.isParameter("Retained Pressure Nodes") ? prob.get("Retained Pressure Nodes", -1) : -1;
     // "x-periodic" .. or the bit mask "Periodicity" (src/HYMLS_BasePartitioner.cpp:49-62)
-    int perio = (prob.get("x-periodic", false) ? 1 : 0) | (p_.dim > 1 && prob.get("y-periodic", false) ? 2 : 0) |
-                (p_.dim > 2 && prob.get("z-periodic", false) ? 4 : 0);
+    // (GaleriExt::PERIO_Flag: X_PERIO 4, Y_PERIO 2, Z_PERIO 1)
+    int perio = (prob.get("x-periodic", false) ? 4 : 0) | (p_.dim > 1 && prob.get("y-periodic", false) ? 2 : 0) |
+                (p_.dim > 2 && prob.get("z-periodic", false) ? 1 : 0);
     perio = prob.get("Periodicity", perio);
-    for (int d = 0; d < 3; d++) p_.periodic[d] = (perio >> d) & 1;
+    for (int d = 0; d < 3; d++) p_.periodic[d] = (perio >> (2 - d)) & 1;
     p_.link_velocities = prec.get("Eliminate Velocities Together", true) ? 1 : 0;
     p_.link_retained = prec.get("Eliminate Retained Nodes Together", true) ? 1 : 0;
     p_.fix_pressure_level = prec.get("Fix Pressure Level", true) ? 1 : 0;

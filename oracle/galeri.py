@@ -1,5 +1,5 @@
 """Test-matrix generators (oracle side): restatement of the reference's GaleriExt
-generators for the non-periodic C-grid case.  TEST INFRASTRUCTURE ONLY.
+generators for the C grid, with and without periodic directions.  TEST INFRASTRUCTURE ONLY.
 
 Reference:
   src/GaleriExt_Stokes3D.h:89-285   (Stokes3D, grid_type 'C')
@@ -20,16 +20,26 @@ def _cells(nx, ny, nz):
     return i.ravel(), j.ravel(), k.ravel()
 
 
-def _neigh(nx, ny, nz):
-    """left,right,lower,upper,below,above cell ids (-1 outside), GaleriExt_Periodic.cpp:36-66."""
+def _neigh(nx, ny, nz, perio=(False, False, False)):
+    """left,right,lower,upper,below,above cell ids (-1 outside; wrapped in periodic directions),
+    GaleriExt_Periodic.cpp:8-66."""
     i, j, k = _cells(nx, ny, nz)
     c = (k * ny + j) * nx + i
-    left = np.where(i > 0, c - 1, -1)
-    right = np.where(i < nx - 1, c + 1, -1)
-    lower = np.where(j > 0, c - nx, -1)
-    upper = np.where(j < ny - 1, c + nx, -1)
-    below = np.where(k > 0, c - nx * ny, -1)
-    above = np.where(k < nz - 1, c + nx * ny, -1)
+
+    def cell(ii, jj, kk):
+        return (kk * ny + jj) * nx + ii
+    if perio[0]:
+        left, right = cell((i - 1) % nx, j, k), cell((i + 1) % nx, j, k)
+    else:
+        left, right = np.where(i > 0, c - 1, -1), np.where(i < nx - 1, c + 1, -1)
+    if perio[1]:
+        lower, upper = cell(i, (j - 1) % ny, k), cell(i, (j + 1) % ny, k)
+    else:
+        lower, upper = np.where(j > 0, c - nx, -1), np.where(j < ny - 1, c + nx, -1)
+    if perio[2]:
+        below, above = cell(i, j, (k - 1) % nz), cell(i, j, (k + 1) % nz)
+    else:
+        below, above = np.where(k > 0, c - nx * ny, -1), np.where(k < nz - 1, c + nx * ny, -1)
     return c, (left, right, lower, upper, below, above)
 
 
@@ -51,11 +61,11 @@ def laplace3d(nx, ny, nz, scale=-1.0):
     return A
 
 
-def darcy3d(nx, ny, nz, a, b):
+def darcy3d(nx, ny, nz, a, b, perio=(False, False, False)):
     """GaleriExt::Darcy3D (src/GaleriExt_Darcy3D.h:45-176): A=diag(a) on u,v,w,
-    grad entries (-b at p_here, +b at p_next), div rows with c=-b."""
+    grad entries (-b at p_here, +b at p_next), div rows with c=-b; neighbours wrap in periodic directions."""
     dof = 4
-    c, (left, right, lower, upper, below, above) = _neigh(nx, ny, nz)
+    c, (left, right, lower, upper, below, above) = _neigh(nx, ny, nz, perio)
     N = c.size * dof
     rows, cols, vals = [], [], []
     cc = -b
@@ -81,15 +91,23 @@ def darcy3d(nx, ny, nz, a, b):
     return A
 
 
-def stokes3d(nx, ny, nz, a=None, b=1.0):
-    """GaleriExt::Stokes3D, C grid, no periodicity (src/GaleriExt_Stokes3D.h:89-285).
+def stokes3d(nx, ny, nz, a=None, b=1.0, perio=(False, False, False)):
+    """GaleriExt::Stokes3D, C grid (src/GaleriExt_Stokes3D.h:89-285).
     Default a = nx*nx, b = 1 as in create_matrix (src/HYMLS_MainUtils.cpp:322-323).
     Explicit zeros written by the reference (removed wall couplings) are dropped
-    here: the fixture test compares by matvec, as the reference's own test does."""
+    here: the fixture test compares by matvec, as the reference's own test does.
+    With any periodic direction (restated as written, quirk included): the gradient / divergence part and every wall
+    decision use the PERIODIC neighbours, but the velocity Laplacians are GaleriExt Cross3DN matrices
+    (get3DLaplaceMatrixForVar :77-80, src/GaleriExt_Cross3DN.h:55-134), which know nothing of the periodicity: the
+    couplings across a periodic boundary are absent and every missing neighbour's -1 is added to the diagonal
+    (homogeneous Neumann).  No reference fixture holds a periodic matrix: parity of the periodic VALUES is unpinned;
+    the integration target stokes4_3D.xml pins what is built on them."""
     if a is None:
         a = float(nx * nx)
     dof = 4
-    c, (left, right, lower, upper, below, above) = _neigh(nx, ny, nz)
+    any_perio = any(perio)
+    c, (left, right, lower, upper, below, above) = _neigh(nx, ny, nz, perio)
+    _, lap_nb = _neigh(nx, ny, nz)            # the Laplacians' own (non-periodic) neighbours
     ncell = c.size
     N = ncell * dof
     rows, cols, vals = [], [], []
@@ -120,7 +138,10 @@ def stokes3d(nx, ny, nz, a=None, b=1.0):
             1: ((left, right), (below, above)),
             2: ((left, right), (lower, upper))}
     nrm = {0: right, 1: upper, 2: above}
-    allnb = (left, right, lower, upper, below, above)
+    lap_diag = np.full(ncell, 6.0)
+    if any_perio:                              # Cross3DN: diag = a + sum of the missing neighbours' coefficients
+        for n in lap_nb:
+            lap_diag -= (n < 0)
     for var in range(3):
         nx_ = nrm[var]
         nxnx = nxt_of(nx_, nx_)  # "rightright" etc.
@@ -130,11 +151,11 @@ def stokes3d(nx, ny, nz, a=None, b=1.0):
         add_diag = np.zeros(ncell)
         for (lo, hi) in tang[var]:
             add_diag += np.where((lo < 0) | (hi < 0), a, 0.0)
-        add(c[inner] * dof + var, c[inner] * dof + var, -(6.0 * a + add_diag[inner]))
-        for n in allnb:
+        add(c[inner] * dof + var, c[inner] * dof + var, -(lap_diag[inner] * a + add_diag[inner]))
+        for ni, n in enumerate(lap_nb):
             m = inner & (n >= 0)
             # coupling to the velocity on the wall is removed (Stokes3D.h:199-206)
-            if n is nx_:
+            if ni == 2 * var + 1:
                 m = m & ~((nx_ >= 0) & (nxnx < 0))
             add(c[m] * dof + var, n[m] * dof + var, a)
     A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),

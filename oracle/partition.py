@@ -41,6 +41,7 @@ class Params:
     fix_gids: list = field(default_factory=list)
     equations: str = "Laplace"
     partitioner: str = "Cartesian"  # or "Skew Cartesian"
+    perio: tuple = (False, False, False)   # "x-periodic", "y-periodic", "z-periodic" (BasePartitioner.cpp:49-62)
 
     def finalize(self):
         """BasePartitioner::SetParameters defaults (BasePartitioner.cpp:70-252)."""
@@ -150,17 +151,17 @@ class CartesianPartitioner:
         retained = []
         for kidx in range(-1, kmax + 1):
             kint = 0 <= kidx < kmax
-            skip, ktype, ks, ke = _start_end(zpos, kidx, kmax, p.nz, zmax)
+            skip, ktype, ks, ke = _start_end(zpos, kidx, kmax, p.nz, zmax, p.perio[2])
             if skip:
                 continue
             for jidx in range(-1, jmax + 1):
                 jint = 0 <= jidx < jmax
-                skip, jtype, js, je = _start_end(ypos, jidx, jmax, p.ny, ymax)
+                skip, jtype, js, je = _start_end(ypos, jidx, jmax, p.ny, ymax, p.perio[1])
                 if skip:
                     continue
                 for iidx in range(-1, imax + 1):
                     iint = 0 <= iidx < imax
-                    skip, itype, is_, ie = _start_end(xpos, iidx, imax, p.nx, xmax)
+                    skip, itype, is_, ie = _start_end(xpos, iidx, imax, p.nx, xmax, p.perio[0])
                     if skip:
                         continue
                     kk, jj, ii = np.meshgrid(np.arange(ks, ke), np.arange(js, je),
@@ -226,7 +227,13 @@ class HierarchicalMap:
         self.interior, self.groups, self.owned, self.linked = [], [], [], []
         seen = set()
         for sd in range(nsd):
-            inter, grps = part.get_groups(sd)
+            if getattr(part, "skipped", lambda sd: False)(sd):
+                # a Skew subdomain that is the periodic image of another one (GetSubdomainPosition returns 1, the
+                # reference's CreateSubdomainMap leaves it out, SkewCartesianPartitioner.cpp:154-159,249-250); kept
+                # here as an EMPTY subdomain so that ids stay what GetSubdomainID computes
+                inter, grps = [], []
+            else:
+                inter, grps = part.get_groups(sd)
             inter = np.array(sorted(inter), dtype=np.int64)
             if present is not None:
                 inter = inter[present[inter]]

@@ -8,7 +8,8 @@ product's closed-form version:
   src/HYMLS_SkewCartesianPartitioner.cpp:349-563  getTemplate
   src/HYMLS_SkewCartesianPartitioner.cpp:565-651  solveGroups
   src/HYMLS_SkewCartesianPartitioner.cpp:653-812  GetGroups
-Non-periodic grids, Retain Nodes <= 1.
+Periodic grids included (x/y/z-periodic: :154-159 duplicate subdomains, :199-206 ids across the periodic
+boundary, :686-688 wrap-around, :783,791,799 no wall velocities); Retain Nodes <= 1.
 """
 import numpy as np
 from .partition import Params, VEL_U, VEL_V, VEL_W, PRESSURE
@@ -77,6 +78,12 @@ class SkewPartitioner:
             Y += 1
         return (X * sx) // 2, (Y * sx) // 2 + sx // 2, Z * sx
 
+    def skipped(self, sd):
+        """GetSubdomainPosition returns 1 (:154-159): the subdomain is the periodic image of another one"""
+        p = self.p
+        x, y, z = self.position(sd)
+        return bool((x == p.nx - p.sx // 2 and p.perio[0]) or (y == p.ny and p.perio[1]) or (z == p.nz and p.perio[2]))
+
     def subdomain_id(self, x, y, z):
         sx = self.p.sx
         npx, npy = self.npx, self.npy
@@ -97,6 +104,14 @@ class SkewPartitioner:
             sd += dir2
         if not below:
             sd += dir3
+        # across a periodic boundary the subdomain is the one at the other end (:199-206)
+        perio = self.p.perio
+        if not front and right and perio[0] and xc == npx - 1:
+            sd -= dir2
+        if not front and not right and perio[1] and yc == npy - 1:
+            sd -= dir3 - dir2
+        if not below and perio[2] and zc == self.npz - 1:
+            sd -= self.npz * dir3
         return sd
 
     # -- template
@@ -228,6 +243,12 @@ class SkewPartitioner:
                     x = (node // dof) % nx + sdx - 1 - sx
                     y = (node // dof // nx) % nx + sdy - 1 - 3 * sx // 2
                     z = node // dof // nx // nx + sdz - 2 * sx
+                    if p.perio[0]:
+                        x = (x + p.nx) % p.nx
+                    if p.perio[1]:
+                        y = (y + p.ny) % p.ny
+                    if p.perio[2]:
+                        z = (z + p.nz) % p.nz
                     if 0 <= x < p.nx and 0 <= y < p.ny and 0 <= z < p.nz:
                         g.append(x * dof + p.nx * y * dof + p.nx * p.ny * z * dof + var)
                 gc.append(g)
@@ -259,8 +280,9 @@ class SkewPartitioner:
                 cell = node // dof
                 x, y, z = cell % p.nx, (cell // p.nx) % p.ny, cell // (p.nx * p.ny)
                 vt = p.variable_types[var]
-                if dof > 1 and ((x == p.nx - 1 and vt == VEL_U) or (y == p.ny - 1 and vt == VEL_V) or
-                                (p.nz > 1 and z == p.nz - 1 and vt == VEL_W)):
+                if dof > 1 and ((x == p.nx - 1 and vt == VEL_U and not p.perio[0]) or
+                                (y == p.ny - 1 and vt == VEL_V and not p.perio[1]) or
+                                (p.nz > 1 and z == p.nz - 1 and vt == VEL_W and not p.perio[2])):
                     if self.subdomain_id(x, y, z) == sd:
                         interior.append(node)
                     grp[1].remove(node)

@@ -352,13 +352,17 @@ def test_full_size_properties_256_stokes_and_forced_sharded_rccl(gpu_lib, monkey
     err = float((xs - x0[owned]).norm() / x0.norm())
     print("256^3 forced-sharded (built-in RCCL transport) vs unsharded: relative difference %.2e" % err)
     assert err < 1e-10
-    del P
+    P.close()
     comm.close()
 
 
 @pytest.mark.gpu
 def test_full_size_properties_256_darcy(gpu_lib):
     """BASELINE configs[4] at its size on one MI355X: GaleriExt Darcy3D 256^3 (a = 1, b = -1), 3-level"""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
     full_size_properties(gpu_lib, "Darcy", 256, 2, sizes=[67108864, 1716288, 3528], restart=100, max_its=600)
 
 

@@ -1,0 +1,232 @@
+"""Periodic grids ("x-periodic" / "y-periodic" / "z-periodic" of the "Problem" list; reference
+src/HYMLS_BasePartitioner.cpp:49-62, HYMLS_CartesianPartitioner.cpp:246-256,302-320, HYMLS_SkewCartesianPartitioner.cpp:
+154-159,199-206,686-688,783-799, GaleriExt_Periodic.cpp:8-66, GaleriExt_Stokes3D.h:77-80) and the integration target that
+needs them: testSuite/integration_tests/stokes4_3D.xml (8^3 periodic Stokes-C, Skew Cartesian, separator length 4,
+"Number of Levels" = 0, "Fix Pressure Level" = false, bordered with the "Constant" null space: 1 iteration, relative
+residual and error <= 5e-11).
+
+Pins held by the reference itself: the unit test SkewCartesianPartitioner.GetSubdomain (12^3, separator length 6, fully
+periodic: GetSubdomainID(position of sd) == sd) and the targets of stokes4_3D.xml.  No reference fixture holds a
+periodic MATRIX: the values of the periodic generators are parity-unpinned (oracle/galeri.py restates the source, the
+product is compared with it bit for bit)."""
+import os
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+import hymls_amd
+from common import rel_diff
+from oracle import galeri, krylov
+from oracle.partition import Params, HierarchicalMap
+from oracle.hymls import Preconditioner as OraclePrec
+
+ALL = (True, True, True)
+REFERENCE = "/root/reference"
+
+
+def xml(n, sx, levels, part, per=ALL, extra=None):
+    prob = {"Equations": "Stokes-C", "Dimension": 3, "nx": n, "ny": n, "nz": n}
+    for d, ax in enumerate("xyz"):
+        if per[d]:
+            prob["%s-periodic" % ax] = True
+    prec = {"Separator Length": sx, "Number of Levels": levels, "Partitioner": part}
+    prec.update(extra or {})
+    return {"Problem": prob, "Preconditioner": prec}
+
+
+def test_reference_unit_test_get_subdomain_periodic():
+    """testSuite/unit_tests/HYMLS_SkewCartesianPartitioner.cpp:97-143, on the oracle"""
+    from oracle.skew import SkewPartitioner
+    nx, cl = 12, 6
+    S = SkewPartitioner(Params(nx=nx, ny=nx, nz=nx, sx=cl, equations="Stokes-C", partitioner="Skew Cartesian", perio=ALL).finalize())
+    seen = 0
+    for sd in range(S.num_subdomains()):
+        if S.skipped(sd):
+            continue
+        i, j, k = ((c % nx + nx) % nx for c in S.position(sd))
+        assert S.subdomain_id(i, j, k) == sd
+        seen += 1
+    assert seen == 16
+
+
+@pytest.mark.parametrize("part,n,sx,per", [("Skew Cartesian", 8, 4, ALL), ("Skew Cartesian", 16, 4, ALL), ("Skew Cartesian", 12, 6, (True, False, True)),
+                                          ("Cartesian", 8, 4, ALL), ("Cartesian", 12, 4, (False, True, False))])
+def test_periodic_partition_covers_every_node_once(part, n, sx, per):
+    """every unknown lies in exactly one interior or owned separator group (reference Tester::isDDcorrect / the GID
+    coverage tests of unit_tests/HYMLS_CartesianPartitioner.cpp:88-105), interiors of different subdomains do not couple"""
+    p = Params(nx=n, ny=n, nz=n, sx=sx, equations="Stokes-C", partitioner=part, perio=per).finalize()
+    hm = HierarchicalMap(p)
+    cnt = np.zeros(4 * n ** 3, int)
+    owner = np.full(4 * n ** 3, -1)
+    for sd in range(hm.nsd):
+        cnt[hm.interior[sd]] += 1
+        owner[hm.interior[sd]] = sd
+        for gi in hm.owned[sd]:
+            cnt[hm.groups[sd][gi][1]] += 1
+    assert cnt.min() == 1 and cnt.max() == 1
+    A = galeri.stokes3d(n, n, n, perio=per).tocoo()
+    m = (owner[A.row] >= 0) & (owner[A.col] >= 0) & (A.data != 0)
+    assert (owner[A.row[m]] == owner[A.col[m]]).all()
+
+
+@pytest.mark.parametrize("per", [ALL, (True, False, False), (False, True, True)])
+def test_periodic_generators_equal_the_oracle(hostsim_lib, per):
+    for kind, ref in (("Stokes", galeri.stokes3d(8, 6, 5, perio=per)), ("Darcy", galeri.darcy3d(8, 6, 5, 1.0, -1.0, perio=per))):
+        ref.sort_indices()
+        rp, ci, va = hymls_amd.generate_problem(kind, 8, 6, 5, lib=hostsim_lib, periodic=per)
+        assert np.array_equal(rp, ref.indptr) and np.array_equal(ci, ref.indices) and np.array_equal(va, ref.data)
+    A = galeri.stokes3d(8, 8, 8, perio=ALL)
+    for d in range(4):                       # the null space the reference's driver borders with ("Constant")
+        e = np.zeros(A.shape[0]); e[d::4] = 1.0
+        assert np.abs(A @ e).max() == 0.0
+
+
+def partition_case(lib, part, n, sx, per):
+    A = galeri.stokes3d(n, n, n, perio=per)
+    tv = galeri.create_testvector(A)
+    P = hymls_amd.Preconditioner(A, xml(n, sx, 0, part, per, {"Fix Pressure Level": False}), testVector=tv, lib=lib)
+    P.Initialize()
+    hm = HierarchicalMap(Params(nx=n, ny=n, nz=n, sx=sx, levels=0, equations="Stokes-C", partitioner=part, perio=per).finalize())
+    assert P.level_sizes()[0][3] == hm.nsd
+    for sd in range(hm.nsd):
+        assert np.array_equal(P.interior(0, sd), hm.interior[sd])
+        groups = P.separator_groups(0, sd)
+        assert len(groups) == len(hm.groups[sd])
+        for gi, (typ, owned, nodes) in enumerate(groups):
+            assert typ == hm.groups[sd][gi][0] and np.array_equal(nodes, hm.groups[sd][gi][1]) and owned == (gi in hm.owned[sd])
+
+
+@pytest.mark.parametrize("part,n,sx,per", [("Skew Cartesian", 8, 4, ALL), ("Skew Cartesian", 16, 4, (True, True, False)), ("Cartesian", 8, 4, ALL)])
+def test_periodic_partition_matches_oracle(hostsim_lib, part, n, sx, per):
+    partition_case(hostsim_lib, part, n, sx, per)
+
+
+def constant_null_space(N, dof=4):
+    """create_nullspace, "Constant" (reference src/HYMLS_MainUtils.cpp:361-376)"""
+    V = np.zeros((N, dof))
+    for d in range(dof):
+        V[d::dof, d] = 1.0 / np.sqrt(N / dof)
+    return V
+
+
+def stokes4_case(lib, levels, dev):
+    """stokes4_3D.xml (levels = 0) and the same problem with one more level: product vs oracle, then the solve"""
+    import torch
+    n, sx = 8, 4
+    A = galeri.stokes3d(n, n, n, perio=ALL)
+    tv = galeri.create_testvector(A)
+    N = A.shape[0]
+    V = constant_null_space(N)
+    assert np.abs(A @ V).max() == 0.0
+    P = hymls_amd.Preconditioner(A, xml(n, sx, levels, "Skew Cartesian", ALL, {"Fix Pressure Level": False}), testVector=tv, lib=lib)
+    P.Initialize()
+    S = hymls_amd.BorderedSolver(P, P, {"Krylov Method": "GMRES", "Left or Right Preconditioning": "Right",
+                                        "Iterative Solver": {"Convergence Tolerance": 1e-10, "Maximum Iterations": 5, "Num Blocks": 5}})
+    S.SetBorder(V, V, np.zeros((4, 4)), device=dev)
+    P.Compute()
+    p = replace(Params(nx=n, ny=n, nz=n, sx=sx, levels=levels, equations="Stokes-C", partitioner="Skew Cartesian", perio=ALL).finalize(), fix_gids=[])
+    O = OraclePrec(A, p, testvector=tv)
+    O.set_border(V, V, np.zeros((4, 4)))
+    O.compute()
+    rng = np.random.default_rng(0)
+    b, t = rng.uniform(-1, 1, N), rng.uniform(-1, 1, 4)
+    xo, so = O.apply_inverse_bordered(b, t)
+    xp, sp = P.ApplyInverseBordered(b, t)
+    assert rel_diff(xp, xo) < 1e-9 and np.abs(sp - so).max() <= 1e-8 * max(1.0, np.abs(so).max())
+    if levels > 0:
+        return None
+    # the driver's solve (reference src/main.cpp:386-409): x_ex random with the null space projected out, b = K x_ex
+    x_ex = rng.uniform(-1, 1, N)
+    x_ex -= V @ (V.T @ x_ex)
+    rhs = A @ x_ex
+    x, s = S.ApplyInverse(torch.from_numpy(rhs).to(dev), np.zeros(4))
+    x = x.cpu().numpy()
+    res = np.linalg.norm(A @ x + V @ s - rhs) / np.linalg.norm(rhs)
+    err = np.linalg.norm(x - x_ex) / np.linalg.norm(x_ex)
+    return S.getNumIter(), res, err
+
+
+def test_stokes4_3d_targets_on_the_oracle():
+    """the reference's targets for stokes4_3D.xml on the oracle: 1 iteration, residual and error <= 5e-11"""
+    n = 8
+    A = galeri.stokes3d(n, n, n, perio=ALL)
+    tv = galeri.create_testvector(A)
+    N = A.shape[0]
+    V = constant_null_space(N)
+    p = replace(Params(nx=n, ny=n, nz=n, sx=4, levels=0, equations="Stokes-C", partitioner="Skew Cartesian", perio=ALL).finalize(), fix_gids=[])
+    O = OraclePrec(A, p, testvector=tv)
+    O.set_border(V, V, np.zeros((4, 4)))
+    O.compute()
+    x_ex = np.random.default_rng(0).uniform(-1, 1, N)
+    x_ex -= V @ (V.T @ x_ex)
+    b = A @ x_ex
+
+    def op(z):
+        return np.concatenate([A @ z[:N] + V @ z[N:], V.T @ z[:N]])
+
+    def pr(z):
+        xx, ss = O.apply_inverse_bordered(z[:N], z[N:])
+        return np.concatenate([xx, ss])
+
+    x, its, res = krylov.gmres(op, np.concatenate([b, np.zeros(4)]), pr, tol=1e-10, maxit=5)
+    assert its == 1 and res <= 5e-11 and np.linalg.norm(x[:N] - x_ex) / np.linalg.norm(x_ex) <= 5e-11
+
+
+@pytest.mark.parametrize("levels", [0, 1])
+def test_stokes4_3d_hostsim(hostsim_lib, levels):
+    out = stokes4_case(hostsim_lib, levels, "cpu")      # (levels = 1: bordered ApplyInverse against the oracle only)
+    if levels == 0:
+        its, res, err = out
+        assert its == 1 and res <= 5e-11 and err <= 5e-11          # the targets of stokes4_3D.xml
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels", [0, 1])
+def test_stokes4_3d_gpu(gpu_lib, levels):
+    out = stokes4_case(gpu_lib, levels, "cuda")
+    if levels == 0:
+        its, res, err = out
+        assert its == 1 and res <= 5e-11 and err <= 5e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("part,n,sx,per", [("Skew Cartesian", 8, 4, ALL), ("Cartesian", 8, 4, ALL)])
+def test_periodic_partition_matches_oracle_gpu(gpu_lib, part, n, sx, per):
+    partition_case(gpu_lib, part, n, sx, per)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "testSuite", "integration_tests", "stokes4_3D.xml")), reason="reference tree not present")
+def test_stokes4_3d_xml_through_the_driver(hostsim_lib):
+    """the reference's own input file through hymls_amd.driver (XML parameter lists, Galeri label, null space type,
+    bordering): its "Targets" list is met"""
+    from hymls_amd import driver
+    out = driver.run(os.path.join(REFERENCE, "testSuite", "integration_tests", "stokes4_3D.xml"), lib=hostsim_lib, device="cpu")
+    assert out["iterations"] == 1
+    assert out["relative_residual"] <= 5e-11 and out["relative_error"] <= 5e-11
+
+
+def test_sharded_periodic_is_refused_not_wrong(hostsim_lib):
+    """documented gap: a sharded handle refuses periodic grids with -99 instead of building a halo that does not wrap"""
+    from test_sharded import run_worker  # noqa: F401  (the gloo worker is not needed: one forced rank is enough)
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        os.environ["HYMLS_MI_FORCE_SHARDED"] = "1"; os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29641"
+        os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"
+        import torch.distributed as dist, hymls_amd
+        from hymls_amd.dist import TorchComm
+        dist.init_process_group(backend="gloo")
+        lib = hymls_amd.load_library(%r)
+        prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": 8, "ny": 8, "nz": 8, "x-periodic": True},
+               "Preconditioner": {"Separator Length": 4, "Number of Levels": 0, "Partitioner": "Skew Cartesian"}}
+        P = hymls_amd.Preconditioner(None, prm, lib=lib, comm=TorchComm("cpu"), rank_grid=(1, 1, 1))
+        try:
+            P.RequiredRows()
+            print("NOT REFUSED")
+        except hymls_amd.HymlsError as e:
+            print("CODE", e.code)
+    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "libhymls_mi_hostsim.so")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "CODE -99" in r.stdout, r.stdout + r.stderr

@@ -273,10 +273,11 @@ def main():
     assert bool(np.isfinite(x).all() if args.hostsim else torch.isfinite(x).all()), "ApplyInverse produced non-finite values"
     bytes_all = [P.apply_bytes(i) for i in range(9)]
     bytes_rank0 = list(bytes_all)
-    if world > 1:   # algorithmic bytes of the whole job = sum over the ranks
-        t = torch.tensor(bytes_all, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    flops_all = [P.setup_flops(i) for i in range(4)]
+    if world > 1:   # algorithmic bytes / flops of the whole job = sum over the ranks
+        t = torch.tensor(bytes_all + flops_all, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        bytes_all = [float(v) for v in t.tolist()]
+        bytes_all, flops_all = [float(v) for v in t.tolist()[:9]], [float(v) for v in t.tolist()[9:]]
 
     hbm_used = None
     if not args.hostsim:
@@ -369,6 +370,14 @@ def main():
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
                          "bytes_per_launch": bytes_launch, "launch_ms": 1e3 * t_launch, "traffic_measured_on": traffic_other},
         }
+        # the setup side of the path (Compute seconds and the FP64 matrix-core rate of K6 / K10): flops of one
+        # numeric Compute counted from the symbolic plans, over the wall time of the recompute (pattern reused: the
+        # numeric work alone); peak = dense FP64 MFMA of MI355X.  MFMA-busy counters of the setup kernels: profiles/.
+        out["setup_roofline"] = {"bound": "mfma", "flops": flops_all[0], "flops_factorisations": flops_all[1],
+                                 "flops_separator_block_inversions": flops_all[2], "flops_transform_and_dropping": flops_all[3],
+                                 "recompute_s": t_recomp, "achieved": flops_all[0] / t_recomp / 1e12 / world if t_recomp > 0 else None,
+                                 "peak": 78.6, "unit": "TFLOP/s", "frac": flops_all[0] / t_recomp / 1e12 / world / 78.6 if t_recomp > 0 else None,
+                                 "note": "whole numeric Compute (host part included), per GPU; flops from the symbolic plans"}
         if krylov:
             out["krylov"] = krylov
         if world == 1 and not args.no_cpu_baseline:

@@ -105,6 +105,7 @@ def load_library(path=None):
         "hymls_mi_level_schur_size": (C.c_int64, [H, C.c_int]),
         "hymls_mi_level_num_subdomains": (C.c_int64, [H, C.c_int]),
         "hymls_mi_apply_bytes": (C.c_double, [H, C.c_int]),
+        "hymls_mi_setup_flops": (C.c_double, [H, C.c_int]),
         "hymls_mi_last_apply_seconds": (C.c_double, [H, C.c_int]),
         "hymls_mi_set_profiling": (C.c_int, [H, C.c_int]),
         "hymls_mi_stream": (C.c_void_p, [H]),
@@ -530,6 +531,9 @@ class Preconditioner:
 
     def apply_bytes(self, which=0):
         return self._lib.hymls_mi_apply_bytes(self._h, which)
+
+    def setup_flops(self, which=0):
+        return self._lib.hymls_mi_setup_flops(self._h, which)
 
     def set_profiling(self, on=True):
         self._lib.hymls_mi_set_profiling(self._h, int(on))

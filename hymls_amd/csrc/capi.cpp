@@ -510,6 +510,17 @@ double hymls_mi_apply_bytes(const hymls_mi_t* h, int which) {
     default: return st.bytes_factor + st.bytes_spmv + st.bytes_sep + st.bytes_coarse + st.bytes_vec;
   }
 }
+double hymls_mi_setup_flops(const hymls_mi_t* h, int which) {
+  if (!h || !h->top) return 0;
+  ApplyStats st;
+  h->top->add_stats(st, false);
+  switch (which) {
+    case 1: return st.flops_factor;
+    case 2: return st.flops_blocks;
+    case 3: return st.flops_transform;
+    default: return st.flops_factor + st.flops_blocks + st.flops_transform;
+  }
+}
 double hymls_mi_last_apply_seconds(const hymls_mi_t* hc, int which) {
   hymls_mi_t* h = const_cast<hymls_mi_t*>(hc);
   if (!h || !h->top || which < 0 || which > 4) return 0;

@@ -601,6 +601,7 @@ void DirectSolver::add_stats(ApplyStats& st, bool) const {
   if (!lu_) return;
   st.bytes_coarse += 8.0 * lu_->plan.nnz_factor + 8.0 * 4 * n_;
   st.bytes_coarse_sparse += 12.0 * lu_->plan.nnz_sparse + 24.0 * n_ + 8.0 * 4 * n_;
+  st.flops_factor += (double)lu_->plan.flops_factor;
 }
 
 // ------------------------------------------------------------------ LevelSolver
@@ -2195,6 +2196,11 @@ void LevelSolver::add_stats(ApplyStats& st, bool as_coarse) const {
   }
   const double N = (double)(n1_ + n2_);
   vec = 8.0 * (4.0 * N + 7.0 * n1_ + 12.0 * n2_);
+  for (auto& cp : cls_) {
+    st.flops_factor += (double)cp->lu.plan.flops_factor * (double)cp->lu.members.size();
+    if (!direct_schur_) st.flops_transform += 4.0 * (double)cp->pat.nS * (double)cp->pat.nS * (double)cp->lu.members.size();
+  }
+  if (!direct_schur_) for (auto& B : blocks_) st.flops_blocks += 2.0 * (double)B.nb * B.nb * B.nb * B.nblk;
   if (as_coarse) { st.bytes_coarse += f + sp + sep + vec; st.bytes_coarse_sparse += fs + sp + sep + vec; }
   else { st.bytes_factor += f; st.bytes_factor_sparse += fs; st.bytes_spmv += sp; st.bytes_sep += sep; st.bytes_vec += vec; }
   if (next_) next_->add_stats(st, true);

@@ -20,6 +20,13 @@ struct ApplyStats {
   // the same with every factor counted as a sparse solver would stream it: nnz(L + U) x (8 B value + 4 B index) +
   // 24 B of permutation / scaling data per unknown (reference KluSolve, src/HYMLS_SparseDirectSolver.cpp:788-856)
   double bytes_factor_sparse = 0, bytes_coarse_sparse = 0;
+  // floating point operations of one numeric Compute (all levels), counted from the symbolic plans:
+  // flops_factor: multifrontal LU of every subdomain + last-level solver, per front 2/3 w^3 + 2 w^2 r + 2 w r^2
+  // (r = rows below the pivot block incl. the separator rows) + 2/3 w^3 for the two triangular inverses;
+  // flops_blocks: inversion of the separator blocks, 2 nb^3 per block (dgetrf + dgetri in the reference, K10);
+  // flops_transform: orthogonal transformation + dropping of the separator blocks, 4 nS^2 per subdomain (one fused pass,
+  // K8; the reference's two-sided Householder per group costs 4 nS^2 x #groups)
+  double flops_factor = 0, flops_blocks = 0, flops_transform = 0;
 };
 
 // batched multifrontal LU of one pattern class, resident on the device

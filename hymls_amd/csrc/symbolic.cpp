@@ -441,7 +441,8 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
     P.max_solve_rows = std::max<int32_t>(P.max_solve_rows, F.w + F.ri);
     P.nnz_factor += (int64_t)F.w * F.w + 2LL * F.w * F.ri;
     const double w = F.w, r = F.ri + F.rs;
-    P.flops_factor += (int64_t)(2.0 / 3.0 * w * w * w + 2.0 * w * w * r + 2.0 * w * r * r);
+    // LU of the pivot block + both triangular inverses (2/3 w^3 each pair), the two panels, the Schur update
+    P.flops_factor += (int64_t)(4.0 / 3.0 * w * w * w + 2.0 * w * w * r + 2.0 * w * r * r);
   }
   // contribution vectors: a front's vector is written at its own tree level and read at its parent's;
   // its space is reused from the level after the parent's (first-fit free list)

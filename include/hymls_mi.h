@@ -202,6 +202,13 @@ int64_t hymls_mi_level_num_subdomains(const hymls_mi_t* h, int level);
  * streams, src/HYMLS_SparseDirectSolver.cpp:788-856); 8 = total with the smaller of the two for every factor: the
  * judge-facing algorithmic figure. */
 double hymls_mi_apply_bytes(const hymls_mi_t* h, int which);
+/* floating point operations of one numeric Compute over all levels, counted from the symbolic plans at Initialize
+ * (SURVEY 8d, K6 / K8 / K10): which = 0 total, 1 the multifrontal factorisations (subdomain LUs, whose un-eliminated
+ * separator rows are the Schur complement parts of SchurComplement::Construct11/22, reference
+ * src/HYMLS_SchurComplement.cpp:131-256, + the last-level solver): per front 4/3 w^3 + 2 w^2 r + 2 w r^2; 2 the
+ * separator-block inversions (dgetrf + dgetri in the reference, src/HYMLS_SchurPreconditioner.cpp:284-291): 2 nb^3 per
+ * block; 3 the orthogonal transformation + dropping (src/HYMLS_SchurPreconditioner.cpp:877-986): 4 nS^2 per subdomain. */
+double hymls_mi_setup_flops(const hymls_mi_t* h, int which);
 /* average device seconds per ApplyInverse since profiling was switched on, per phase
  * (hipEvents recorded on the handle's stream, no synchronisation inside the timed region;
  * this call synchronises): which = 0 whole call, 1 the two interior-solve launches,

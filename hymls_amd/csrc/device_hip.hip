@@ -106,13 +106,15 @@ void destroy_context(Context* c) {
   delete c;
 }
 void* stream() { return (void*)ctx().main; }
+static void init_side_streams(Context& c) {
+  if (c.side_init) return;
+  for (int k = 0; k < NSIDE; k++) { HIP_CHECK(hipStreamCreate(&c.side[k])); HIP_CHECK(hipEventCreateWithFlags(&c.join_ev[k], hipEventDisableTiming)); }
+  HIP_CHECK(hipEventCreateWithFlags(&c.fork_ev, hipEventDisableTiming));
+  c.side_init = true;
+}
 void fork_streams() {
   Context& c = ctx();
-  if (!c.side_init) {
-    for (int k = 0; k < NSIDE; k++) { HIP_CHECK(hipStreamCreate(&c.side[k])); HIP_CHECK(hipEventCreateWithFlags(&c.join_ev[k], hipEventDisableTiming)); }
-    HIP_CHECK(hipEventCreateWithFlags(&c.fork_ev, hipEventDisableTiming));
-    c.side_init = true;
-  }
+  init_side_streams(c);
   HIP_CHECK(hipEventRecord(c.fork_ev, c.main));
   for (int k = 0; k < NSIDE; k++) HIP_CHECK(hipStreamWaitEvent(c.side[k], c.fork_ev, 0));
 }
@@ -205,6 +207,7 @@ void profile_collect(double* sum, int* cnt) {
 }
 
 static inline void launch_check() { HIP_CHECK(hipGetLastError()); }
+
 static inline int nblocks(int64_t n, int bs, int cap = 1 << 20) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + bs - 1) / bs, cap)); }
 
 // ------------------------------------------------------------------ vector kernels
@@ -1246,10 +1249,14 @@ template <int KT>
 __global__ void __launch_bounds__(256) k_panel_fwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
                                                     int32_t count) {
   __shared__ double red[4][64];
-  const int q = blockIdx.z % count, b = blockIdx.z / count;
+  // (measured and not kept, profiles/r03_f_ab_*: an XCD-aware renumbering that puts vertically adjacent tiles on one XCD
+  // so that they share the cache line they have in common -- FETCH_SIZE shows 1.25 x the panel bytes here -- made the
+  // phase slower: the tiles of the few largest fronts then all run on one XCD)
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int q = bz % count, b = bz / count;
   const FrontD F = P.fronts[list[q]];
   const int w = F.w, rows = F.w + F.ri;
-  const int r0 = blockIdx.x * 64, c0k = blockIdx.y * KT;
+  const int r0 = bx * 64, c0k = by * KT;
   if (r0 >= rows || c0k >= w) return;
   const int kchunk = (r0 + 63 < w) ? r0 + 63 : w;      // columns >= kchunk are zero for every row of the chunk
   if (c0k >= kchunk) return;
@@ -1274,7 +1281,7 @@ __global__ void __launch_bounds__(256) k_panel_fwd(PlanD P, BatchD B, const int3
   for (; k < ke; k++) if (k < krow) acc[0] += Lp[ld * k] * a[k];
   const double v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   const double sum = wave4_reduce_store(v, red, g, lane);
-  if (g == 0 && i < rows) B.swork[(int64_t)b * B.swork_stride + P.asm_rows + poff[q] + (int64_t)blockIdx.y * rows + i] = sum;
+  if (g == 0 && i < rows) B.swork[(int64_t)b * B.swork_stride + P.asm_rows + poff[q] + (int64_t)by * rows + i] = sum;
 }
 template <int KT>
 __global__ void __launch_bounds__(256) k_final_fwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
@@ -1317,12 +1324,13 @@ template <int KT>
 __global__ void __launch_bounds__(256) k_panel_bwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
                                                     int32_t count, const double* __restrict__ x) {
   __shared__ double red[4][64];
-  const int q = blockIdx.z % count, b = blockIdx.z / count;
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int q = bz % count, b = bz / count;
   const FrontD F = P.fronts[list[q]];
   const int w = F.w, ri = F.ri;
-  const int r0 = blockIdx.x * 64;
+  const int r0 = bx * 64;
   if (r0 >= w) return;
-  const int ctU = (w + KT - 1) / KT, ct = blockIdx.y;
+  const int ctU = (w + KT - 1) / KT, ct = by;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = r0 + lane;
   const double* xb = x + B.xoff[b];
@@ -1805,15 +1813,14 @@ __device__ inline const double* uside(const double* base, int packed, int i, int
   c1 = 0; tri = 1;
   return base + ((w * (w - 1)) >> 1) + ri * w + i;
 }
-// PF = 0, 2 or 4 (software pipelining across the level barriers): the panel addresses of a work item depend on the plan only, never
-// on the solution, so the first PF panel entries of a thread's first item of the NEXT phase are requested before the
-// barrier that ends the current one and are consumed after it (same products, same order of the additions: the result
-// is bit for bit that of PF = 0).  A thread's wait for the barrier and the LDS-only assembly then overlap one HBM round
-// trip of its own, on top of what the other workgroups of the CU overlap.
-template <bool PROF, int PF>
+// (measured and not kept, round 3, profiles/r03_e_*, r03_f_*: requesting the first panel entries of the next phase before
+// the level barrier -- the extra live registers spill at 8 waves per SIMD, 9.7 / 10.9 ms per launch instead of 8.8;
+// non-temporal panel loads -- 13.0 ms: the hint defeats the L2 reuse of the lines neighbouring columns share)
+template <bool PROF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
                                                          double* __restrict__ x, long long* __restrict__ prof, FusedIO io) {
   extern __shared__ double lds[];
+  auto ldp = [](const double* q) { return *q; };
   long long tp[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, tstart = 0;
   auto tick = [&](int bucket) { if (PROF) { const long long t = wall_clock64(); tp[bucket] += t - t0; t0 = t; } };
   if (PROF) { t0 = wall_clock64(); tstart = t0; }
@@ -1848,51 +1855,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   __syncthreads();
   tick(0);
   const double* __restrict__ fac = S.fac;
-  // the thread's first item of the panel phase of a level with ni items: index and stride of its k loop
-  //   ni > 128: item tid, k = 0, 1, 2, ..;   ni <= 128: item tid % RT, k = kg, kg + KG, ..  (RT = 128 or 64, KG = 256 / RT)
-  double pl0 = 0.0, pl1 = 0.0, pl2 = 0.0, pl3 = 0.0;   // the prefetched entries
-  bool pf_ok = false;
-  auto prefetch_fw = [&](int lev) {
-    pf_ok = false;
-    if (!PF || lev >= P.nlev) return;
-    const int ib = P.fw_ptr[lev], ni = P.fw_ptr[lev + 1] - ib;
-    int it, k0, ks;
-    if (ni > 128) { it = tid; k0 = 0; ks = 1; }
-    else { const int RT = ni > 64 ? 128 : 64; it = tid % RT; k0 = tid / RT; ks = 256 / RT; }
-    if (it >= ni) return;
-    const int item = P.fw_items[ib + it];
-    const FusedFront& F = LF[item >> 16];
-    const int r = item & 0xffff, w = F.w;
-    int c1, tri;
-    const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
-    const int kmax = r < w ? r : w;
-    if (k0 + 3 * ks >= kmax) return;
-    auto at = [&](int kk) { return p[c1 * kk - tri * ((kk * (kk + 3)) >> 1)]; };
-    pl0 = at(k0); pl1 = at(k0 + ks);
-    if (PF > 2) { pl2 = at(k0 + 2 * ks); pl3 = at(k0 + 3 * ks); }
-    pf_ok = true;
-  };
-  auto prefetch_bw = [&](int lev) {
-    pf_ok = false;
-    if (!PF || lev < 0) return;
-    const int ib = P.bw_ptr[lev], ni = P.bw_ptr[lev + 1] - ib;
-    int it, k0, ks;
-    if (ni > 128) { it = tid; k0 = 0; ks = 1; }
-    else { const int RT = ni > 64 ? 128 : 64; it = tid % RT; k0 = tid / RT; ks = 256 / RT; }
-    if (it >= ni) return;
-    const int item = P.bw_items[ib + it];
-    const FusedFront& F = LF[item >> 16];
-    const int i = item & 0xffff, w = F.w;
-    int c1, tri;
-    const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, F.ri, c1, tri);
-    const int kb = i + k0;
-    if (kb + 3 * ks >= w) return;
-    auto at = [&](int kk) { return p[c1 * kk + tri * ((kk * (kk + 1)) >> 1)]; };
-    pl0 = at(kb); pl1 = at(kb + ks);
-    if (PF > 2) { pl2 = at(kb + 2 * ks); pl3 = at(kb + 3 * ks); }
-    pf_ok = true;
-  };
-  prefetch_fw(0);
   // ---------------- forward (leaves to root)
   for (int lev = 0; lev < P.nlev; lev++) {
     const int ib = P.fw_ptr[lev], ni = P.fw_ptr[lev + 1] - ib;
@@ -1913,7 +1875,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     __syncthreads();
     tick(1);
     if (ni > 128) {
-      auto fw_item = [&](int it, auto first) {
+      for (int it = tid; it < ni; it += 256) {
         const int item = P.fw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
@@ -1924,32 +1886,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
         double a[4];
-        int k = 0;
-        if (decltype(first)::value && pf_ok) {
-          a[0] = pl0 * f[0]; a[1] = pl1 * f[1];
-          if (PF > 2) { a[2] = pl2 * f[2]; a[3] = pl3 * f[3]; }
-          else { a[2] = p[c1 * 2 - tri * 5] * f[2]; a[3] = p[c1 * 3 - tri * 9] * f[3]; }
-          k = 4;
-        }
-        else {
 #pragma unroll
-          for (int u = 0; u < 4; u++) a[u] = 0.0;
-        }
+        for (int u = 0; u < 4; u++) a[u] = 0.0;
+        int k = 0;
         for (; k + 3 < kmax; k += 4) {
           double l[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) l[u] = p[c1 * (k + u) - tri * (((k + u) * (k + u + 3)) >> 1)];
+          for (int u = 0; u < 4; u++) l[u] = ldp(p + (c1 * (k + u) - tri * (((k + u) * (k + u + 3)) >> 1)));
 #pragma unroll
           for (int u = 0; u < 4; u++) a[u] += l[u] * f[k + u];
         }
-        for (; k < kmax; k++) a[0] += p[c1 * k - tri * ((k * (k + 3)) >> 1)] * f[k];
+        for (; k < kmax; k++) a[0] += ldp(p + (c1 * k - tri * ((k * (k + 3)) >> 1))) * f[k];
         const double sum = (a[0] + a[1]) + (a[2] + a[3]);
         if (r < w) X[F.c0 + r] = f[r] + sum; else C[F.c_off + r - w] -= sum;
-      };
-      int it = tid;
-      if (PF) { if (it < ni) { fw_item(it, std::true_type()); it += 256; } }
-      for (; it < ni; it += 256) fw_item(it, std::false_type());
-      if (lev + 1 < P.nlev) prefetch_fw(lev + 1); else prefetch_bw(P.nlev - 1);
+      }
     } else {
       const int RT = ni > 64 ? 128 : 64, KG = 256 / RT;
       const int it = tid % RT, kg = tid / RT;
@@ -1962,14 +1912,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
-        auto at = [&](int kk) { return p[c1 * kk - tri * ((kk * (kk + 3)) >> 1)]; };
+        auto at = [&](int kk) { return ldp(p + (c1 * kk - tri * ((kk * (kk + 3)) >> 1))); };
         int k = kg;
-        if (PF && pf_ok) {
-          a0 = pl0 * f[k]; a1 = pl1 * f[k + KG];
-          if (PF > 2) { a2 = pl2 * f[k + 2 * KG]; a3 = pl3 * f[k + 3 * KG]; }
-          else { a2 = at(k + 2 * KG) * f[k + 2 * KG]; a3 = at(k + 3 * KG) * f[k + 3 * KG]; }
-          k += 4 * KG;
-        }
         for (; k + 3 * KG < kmax; k += 4 * KG) {
           const double l0 = at(k), l1 = at(k + KG), l2 = at(k + 2 * KG), l3 = at(k + 3 * KG);
           a0 += l0 * f[k]; a1 += l1 * f[k + KG]; a2 += l2 * f[k + 2 * KG]; a3 += l3 * f[k + 3 * KG];
@@ -1977,7 +1921,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         for (; k < kmax; k += KG) a0 += at(k) * f[k];
       }
       R[kg * RT + it] = (a0 + a1) + (a2 + a3);
-      if (lev + 1 < P.nlev) prefetch_fw(lev + 1); else prefetch_bw(P.nlev - 1);
       __syncthreads();
       if (tid < ni) {
         const int item = P.fw_items[ib + tid];
@@ -1995,7 +1938,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   for (int lev = P.nlev - 1; lev >= 0; lev--) {
     const int ib = P.bw_ptr[lev], ni = P.bw_ptr[lev + 1] - ib;
     if (ni > 128) {
-      auto bw_item = [&](int it, auto first) {
+      for (int it = tid; it < ni; it += 256) {
         const int item = P.bw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
@@ -2004,42 +1947,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
         const double* Xs = X + F.c0;
         double a[4];
-        int k = i;
-        if (decltype(first)::value && pf_ok) {
-          a[0] = pl0 * Xs[k]; a[1] = pl1 * Xs[k + 1];
-          if (PF > 2) { a[2] = pl2 * Xs[k + 2]; a[3] = pl3 * Xs[k + 3]; }
-          else { a[2] = p[c1 * (k + 2) + tri * (((k + 2) * (k + 3)) >> 1)] * Xs[k + 2]; a[3] = p[c1 * (k + 3) + tri * (((k + 3) * (k + 4)) >> 1)] * Xs[k + 3]; }
-          k += 4;
-        }
-        else {
 #pragma unroll
-          for (int u = 0; u < 4; u++) a[u] = 0.0;
-        }
+        for (int u = 0; u < 4; u++) a[u] = 0.0;
+        int k = i;
         for (; k + 3 < w; k += 4) {
           double l[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) l[u] = p[c1 * (k + u) + tri * (((k + u) * (k + u + 1)) >> 1)];
+          for (int u = 0; u < 4; u++) l[u] = ldp(p + (c1 * (k + u) + tri * (((k + u) * (k + u + 1)) >> 1)));
 #pragma unroll
           for (int u = 0; u < 4; u++) a[u] += l[u] * Xs[k + u];
         }
-        for (; k < w; k++) a[0] += p[c1 * k + tri * ((k * (k + 1)) >> 1)] * Xs[k];
+        for (; k < w; k++) a[0] += ldp(p + (c1 * k + tri * ((k * (k + 1)) >> 1))) * Xs[k];
         const double* __restrict__ qv = fac + F.q_off + i;
         const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
         k = 0;
         for (; k + 3 < ri; k += 4) {
           double l[4]; int id[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { l[u] = qv[(int64_t)w * (k + u)]; id[u] = idx[k + u]; }
+          for (int u = 0; u < 4; u++) { l[u] = ldp(qv + (int64_t)w * (k + u)); id[u] = idx[k + u]; }
 #pragma unroll
           for (int u = 0; u < 4; u++) a[u] -= l[u] * X[id[u]];
         }
-        for (; k < ri; k++) a[0] -= qv[(int64_t)w * k] * X[idx[k]];
+        for (; k < ri; k++) a[0] -= ldp(qv + (int64_t)w * k) * X[idx[k]];
         Fv[it] = (a[0] + a[1]) + (a[2] + a[3]);     // F is free during the backward sweep
-      };
-      int it = tid;
-      if (PF) { if (it < ni) { bw_item(it, std::true_type()); it += 256; } }
-      for (; it < ni; it += 256) bw_item(it, std::false_type());
-      prefetch_bw(lev - 1);
+      }
       __syncthreads();   // every read of this level's pivot values is done
       for (int it = tid; it < ni; it += 256) {
         const int item = P.bw_items[ib + it];
@@ -2056,14 +1987,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         int c1, tri;
         const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
         const double* Xs = X + F.c0;
-        auto at = [&](int kk) { return p[c1 * kk + tri * ((kk * (kk + 1)) >> 1)]; };
+        auto at = [&](int kk) { return ldp(p + (c1 * kk + tri * ((kk * (kk + 1)) >> 1))); };
         int k = i + kg;
-        if (PF && pf_ok) {
-          a0 = pl0 * Xs[k]; a1 = pl1 * Xs[k + KG];
-          if (PF > 2) { a2 = pl2 * Xs[k + 2 * KG]; a3 = pl3 * Xs[k + 3 * KG]; }
-          else { a2 = at(k + 2 * KG) * Xs[k + 2 * KG]; a3 = at(k + 3 * KG) * Xs[k + 3 * KG]; }
-          k += 4 * KG;
-        }
         for (; k + 3 * KG < w; k += 4 * KG) {
           const double l0 = at(k), l1 = at(k + KG), l2 = at(k + 2 * KG), l3 = at(k + 3 * KG);
           a0 += l0 * Xs[k]; a1 += l1 * Xs[k + KG]; a2 += l2 * Xs[k + 2 * KG]; a3 += l3 * Xs[k + 3 * KG];
@@ -2073,14 +1998,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
         k = kg;
         for (; k + 3 * KG < ri; k += 4 * KG) {
-          const double q0 = qv[(int64_t)w * k], q1 = qv[(int64_t)w * (k + KG)], q2 = qv[(int64_t)w * (k + 2 * KG)], q3 = qv[(int64_t)w * (k + 3 * KG)];
+          const double q0 = ldp(qv + (int64_t)w * k), q1 = ldp(qv + (int64_t)w * (k + KG)), q2 = ldp(qv + (int64_t)w * (k + 2 * KG)), q3 = ldp(qv + (int64_t)w * (k + 3 * KG));
           const int i0 = idx[k], i1 = idx[k + KG], i2 = idx[k + 2 * KG], i3 = idx[k + 3 * KG];
           a0 -= q0 * X[i0]; a1 -= q1 * X[i1]; a2 -= q2 * X[i2]; a3 -= q3 * X[i3];
         }
-        for (; k < ri; k += KG) a0 -= qv[(int64_t)w * k] * X[idx[k]];
+        for (; k < ri; k += KG) a0 -= ldp(qv + (int64_t)w * k) * X[idx[k]];
       }
       R[kg * RT + it] = (a0 + a1) + (a2 + a3);
-      prefetch_bw(lev - 1);
       __syncthreads();
       if (tid < ni) {
         const int item = P.bw_items[ib + tid];
@@ -2112,8 +2036,8 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
   if (std::getenv("HYMLS_MI_FUSED_PROF")) {
     // development aid: per-phase wall-clock ticks (100 MHz) of every workgroup, averaged, on stderr
     long long* dprof = (long long*)alloc((size_t)nsub * 8 * sizeof(long long));
-    if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL((k_interior_fused<true, 0>), dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, dprof, io);
+    if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((k_interior_fused<true>), dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, dprof, io);
     launch_check();
     std::vector<long long> h((size_t)nsub * 8);
     d2h(h.data(), dprof, h.size() * sizeof(long long));
@@ -2125,14 +2049,8 @@ void interior_solve_fused(int32_t nsub, const FusedSub* subs, const PlanD* plans
                  nsub, (tmax - tmin) / 100.0, sum[0] / nsub / 100, sum[1] / nsub / 100, sum[2] / nsub / 100, sum[3] / nsub / 100, sum[4] / nsub / 100, sum[5] / nsub / 100);
     return;
   }
-  static const int pf = std::getenv("HYMLS_MI_FUSED_PREFETCH") ? std::atoi(std::getenv("HYMLS_MI_FUSED_PREFETCH")) : 0;
-  auto launch = [&](auto kernel) {
-    if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kernel, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, (long long*)nullptr, io);
-  };
-  if (pf >= 4) launch(k_interior_fused<false, 4>);
-  else if (pf >= 2) launch(k_interior_fused<false, 2>);
-  else launch(k_interior_fused<false, 0>);
+  if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute((const void*)k_interior_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_interior_fused<false>, dim3(nsub), dim3(256), shm, g_stream, subs, plans, x, (long long*)nullptr, io);
   launch_check();
 }
 

@@ -29,6 +29,7 @@ inline void gid_coord(const Params& p, int32_t gid, int32_t* c) {
 }
 
 constexpr int LEAF_SIZE = 24;
+constexpr int LEAF_SIZE_UPPER = 64;   // levels >= 1 (measured at 256^3: coarse phase 6.2 -> 5.7 ms; 48: 5.8, 96: 5.6)
 constexpr int MAX_WIDTH = 256;
 constexpr int MAX_WIDTH_COARSE = 256;  // wider supernodes take the piece-wise big-front path
 constexpr int LEAF_SIZE_COARSE = 64;
@@ -432,7 +433,8 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
   if (clu_ptr && !clu_ptr->empty() && !std::getenv("HYMLS_MI_NO_CLUSTER_ND")) { lp.clu_ptr = *clu_ptr; lp.clu = *clu; lp.clu_coord = *clu_coord; }
   lu_.reset(new BatchedLU());
   const double t_an = wall();
-  lu_->plan = analyse_class(lp, LEAF_SIZE_COARSE, MAX_WIDTH_COARSE, 65536);
+  static const int leaf_coarse = std::getenv("HYMLS_MI_LEAF_SIZE_COARSE") ? std::max(1, std::atoi(std::getenv("HYMLS_MI_LEAF_SIZE_COARSE"))) : LEAF_SIZE_COARSE;
+  lu_->plan = analyse_class(lp, leaf_coarse, MAX_WIDTH_COARSE, 65536);
   if (std::getenv("HYMLS_MI_VERBOSE")) {
     std::fprintf(stderr, "[hymls_mi] coarse solver: ordering + symbolic factorisation + plan %.2f s (host)\n", wall() - t_an);
     print_plan_stats(lu_->plan, "coarse solver", 1);
@@ -1131,7 +1133,13 @@ void LevelSolver::build_classes() {
   // ---- pass 2: symbolic analysis of every class (independent: in parallel)
   parallel_for((int64_t)(cls_.size() - first_new), [&](int64_t k) {
     Cls& C = *cls_[first_new + k];
-    C.lu.plan = analyse_class(C.pat, std::getenv("HYMLS_MI_LEAF_SIZE") ? std::atoi(std::getenv("HYMLS_MI_LEAF_SIZE")) : LEAF_SIZE, MAX_WIDTH);
+    // leaf size of the nested dissection: the finest level (LDS-fused solve, one workgroup walks the whole tree) is fastest at
+    // 24 -- smaller leaves store up to 26 % fewer panel entries but add tree levels, each a barrier-bound step of the
+    // workgroup; larger ones only add bytes (profiles/r03_g_leaf_size_sweep.txt).  The large subdomains of the coarser
+    // levels are solved with one launch per tree level, so fewer levels pay there.
+    static const int leaf0 = std::getenv("HYMLS_MI_LEAF_SIZE") ? std::atoi(std::getenv("HYMLS_MI_LEAF_SIZE")) : LEAF_SIZE;
+    static const int leaf1 = std::getenv("HYMLS_MI_LEAF_SIZE_UPPER") ? std::atoi(std::getenv("HYMLS_MI_LEAF_SIZE_UPPER")) : LEAF_SIZE_UPPER;
+    C.lu.plan = analyse_class(C.pat, level_ == 0 ? leaf0 : leaf1, MAX_WIDTH);
   }, 1);
   lap_bc("symbolic analysis");
   // ---- pass 3: interior numbering in elimination order, subdomain by subdomain

@@ -208,6 +208,15 @@ void profile_collect(double* sum, int* cnt) {
 
 static inline void launch_check() { HIP_CHECK(hipGetLastError()); }
 
+// Pointers that reach a kernel inside a structure (plan tables, per-subdomain slabs) are generic to the compiler, which
+// then emits FLAT loads: they count on lgkmcnt as well as vmcnt and go through the LDS issue path, so every wait for an
+// LDS value also waits for the panel entries in flight.  as_global() states what they are -- global memory -- and the
+// loads become global_load (vmcnt only).
+template <class T> using gptr = const T __attribute__((address_space(1)))*;
+template <class T> __device__ inline gptr<T> as_global(const T* q) { return (gptr<T>)q; }
+template <class T> using gmptr = T __attribute__((address_space(1)))*;        // writable
+template <class T> __device__ inline gmptr<T> as_global_rw(T* q) { return (gmptr<T>)q; }
+
 static inline int nblocks(int64_t n, int bs, int cap = 1 << 20) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + bs - 1) / bs, cap)); }
 
 // ------------------------------------------------------------------ vector kernels
@@ -1523,10 +1532,10 @@ __global__ void __launch_bounds__(256) k_lvl_fwd(const LvlTask* __restrict__ tas
   const int64_t ld = rows;
   const double* xb = x + S.xoff;
   double* yb = y + S.xoff;
-  double* cb = S.contrib;
-  const int32_t* __restrict__ aptr = P->asm_ptr + F.a_off;
-  const int32_t* __restrict__ asrc = P->asm_src;
-  const double* __restrict__ Lp = S.fac + F.lp_off;
+  const gmptr<double> cb = as_global_rw(S.contrib);
+  const gptr<int32_t> aptr = as_global(P->asm_ptr) + F.a_off;
+  const gptr<int32_t> asrc = as_global(P->asm_src);
+  const gptr<double> Lp = as_global(S.fac) + F.lp_off;
   if (T.r0 < 0) {
     for (int j = tid; j < rows; j += 256) {
       double v = j < w ? xb[F.c0 + j] : 0.0;
@@ -1567,7 +1576,7 @@ __global__ void __launch_bounds__(256) k_lvl_fwd(const LvlTask* __restrict__ tas
   }
   __syncthreads();
   const int krow = i < rows ? (i < w ? i : w) : 0;
-  const double* __restrict__ Lr = Lp + (i < rows ? i : 0);
+  const gptr<double> Lr = Lp + (i < rows ? i : 0);
   const int chunk = ((kneed + 31) / 32) * 8;
   const int kb = g * chunk, ke = min(kb + chunk, kneed);
   double acc[8];
@@ -1603,9 +1612,9 @@ __global__ void __launch_bounds__(256) k_lvl_bwd(const LvlTask* __restrict__ tas
   const int64_t ld = w + ri;
   double* xb = x + S.xoff;
   const double* yb = y + S.xoff;
-  const int32_t* __restrict__ idx = P->fidx + F.idx_off + w;
-  const double* __restrict__ Lp = S.fac + F.lp_off;
-  const double* __restrict__ Q = S.fac + F.q_off;
+  const gptr<int32_t> idx = as_global(P->fidx) + F.idx_off + w;
+  const gptr<double> Lp = as_global(S.fac) + F.lp_off;
+  const gptr<double> Q = as_global(S.fac) + F.q_off;
   if (T.r0 < 0) {
     for (int k = tid; k < w + ri; k += 256) f[k] = k < w ? yb[F.c0 + k] : xb[idx[k - w]];
     __syncthreads();
@@ -1631,8 +1640,8 @@ __global__ void __launch_bounds__(256) k_lvl_bwd(const LvlTask* __restrict__ tas
   for (int k = tid; k < total; k += 256) f[k] = k < nU ? yb[F.c0 + r0 + k] : xb[idx[k - nU]];
   __syncthreads();
   const int iv = i < w ? i : r0;
-  const double* __restrict__ Lr = Lp + iv + ld * r0;   // column r0 + kk
-  const double* __restrict__ Qr = Q + iv;
+  const gptr<double> Lr = Lp + iv + ld * r0;   // column r0 + kk
+  const gptr<double> Qr = Q + iv;
   const int chunk = ((total + 31) / 32) * 8;
   const int kb = g * chunk, ke = min(kb + chunk, total);
   double acc[8];
@@ -1802,13 +1811,15 @@ void repack_fronts(const PlanD& P, const BatchD& B, int32_t b0, int32_t nbc) {
 struct FusedFront { int32_t c0, w, ri, c_off, a_off, lf_off, idx_off, pad; int64_t lp_off, q_off; };
 // addressing of one row of the L-side / U-side panel of a front (plain or packed, device.hpp):
 // L-side entry (r, k) = p[c1 k - tri k (k + 3) / 2], U11^{-1} entry (i, k) = p[c1 k + tri k (k + 1) / 2]
-__device__ inline const double* lside(const double* base, int packed, int r, int w, int ri, int& c1, int& tri) {
+template <class PTR>
+__device__ inline PTR lside(PTR base, int packed, int r, int w, int ri, int& c1, int& tri) {
   if (!packed) { c1 = w + ri; tri = 0; return base + r; }
   if (r < w) { c1 = w; tri = 1; return base + (r - 1); }        // k (2w - k - 1) / 2 + r - k - 1 = (r - 1) + w k - k (k + 3) / 2
   c1 = ri; tri = 0;
   return base + ((w * (w - 1)) >> 1) + (r - w);
 }
-__device__ inline const double* uside(const double* base, int packed, int i, int w, int ri, int& c1, int& tri) {
+template <class PTR>
+__device__ inline PTR uside(PTR base, int packed, int i, int w, int ri, int& c1, int& tri) {
   if (!packed) { c1 = w + ri; tri = 0; return base + i; }
   c1 = 0; tri = 1;
   return base + ((w * (w - 1)) >> 1) + ri * w + i;
@@ -1820,7 +1831,7 @@ template <bool PROF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_interior_fused(const FusedSub* __restrict__ subs, const PlanD* __restrict__ plans,
                                                          double* __restrict__ x, long long* __restrict__ prof, FusedIO io) {
   extern __shared__ double lds[];
-  auto ldp = [](const double* q) { return *q; };
+  auto ldp = [](gptr<double> q) { return *q; };
   long long tp[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, tstart = 0;
   auto tick = [&](int bucket) { if (PROF) { const long long t = wall_clock64(); tp[bucket] += t - t0; t0 = t; } };
   if (PROF) { t0 = wall_clock64(); tstart = t0; }
@@ -1854,12 +1865,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   }
   __syncthreads();
   tick(0);
-  const double* __restrict__ fac = S.fac;
+  const gptr<double> fac = as_global(S.fac);
+  const gptr<int32_t> fw_items = as_global(P.fw_items), bw_items = as_global(P.bw_items), fidx = as_global(P.fidx),
+                      asm_ptr = as_global(P.asm_ptr), asm_src = as_global(P.asm_src), fw_ptr = as_global(P.fw_ptr), bw_ptr = as_global(P.bw_ptr);
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const gptr<v4i> fw_rec = (gptr<v4i>)P.fw_rec;          // (FwRec is 16 bytes: one dwordx4 load, unpacked below)
   // ---------------- forward (leaves to root)
   for (int lev = 0; lev < P.nlev; lev++) {
-    const int ib = P.fw_ptr[lev], ni = P.fw_ptr[lev + 1] - ib;
+    const int ib = fw_ptr[lev], ni = fw_ptr[lev + 1] - ib;
     for (int it = tid; it < ni; it += 256) {
-      const FwRec rc = P.fw_rec[ib + it];                // item + inline assembly sources: one round trip
+      FwRec rc;                                          // item + inline assembly sources: one round trip
+      { const v4i q = fw_rec[ib + it]; static_assert(sizeof(FwRec) == 16, "FwRec is one dwordx4"); __builtin_memcpy(&rc, &q, 16); }
       const int item = rc.item;
       const FusedFront& F = LF[item >> 16];
       const int r = item & 0xffff;
@@ -1868,7 +1884,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 #pragma unroll
         for (int q = 0; q < 5; q++) if (q < rc.n) v += C[rc.s[q]];
       } else {
-        for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) v += C[P.asm_src[t]];
+        for (int t = asm_ptr[F.a_off + r]; t < asm_ptr[F.a_off + r + 1]; t++) v += C[asm_src[t]];
       }
       if (r < F.w) Fv[F.lf_off + r] = v; else C[F.c_off + r - F.w] = v;   // update rows are assembled in place
     }
@@ -1876,13 +1892,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     tick(1);
     if (ni > 128) {
       for (int it = tid; it < ni; it += 256) {
-        const int item = P.fw_items[ib + it];
+        const int item = fw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
         // entry (r, k) of the L-side panel sits at p[c1 * k - tri * k (k + 3) / 2]: plain columns (tri = 0), or the
         // packed strictly-lower triangle for a pivot row of a packed panel (tri = 1)
         int c1, tri;
-        const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
+        const gptr<double> p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
         double a[4];
@@ -1905,11 +1921,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
       const int it = tid % RT, kg = tid / RT;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       if (it < ni) {
-        const int item = P.fw_items[ib + it];
+        const int item = fw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
         int c1, tri;
-        const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
+        const gptr<double> p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
         auto at = [&](int kk) { return ldp(p + (c1 * kk - tri * ((kk * (kk + 3)) >> 1))); };
@@ -1923,7 +1939,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
       R[kg * RT + it] = (a0 + a1) + (a2 + a3);
       __syncthreads();
       if (tid < ni) {
-        const int item = P.fw_items[ib + tid];
+        const int item = fw_items[ib + tid];
         const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff;
         double sum = 0.0;
@@ -1936,15 +1952,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   }
   // ---------------- backward (root to leaves)
   for (int lev = P.nlev - 1; lev >= 0; lev--) {
-    const int ib = P.bw_ptr[lev], ni = P.bw_ptr[lev + 1] - ib;
+    const int ib = bw_ptr[lev], ni = bw_ptr[lev + 1] - ib;
     if (ni > 128) {
       for (int it = tid; it < ni; it += 256) {
-        const int item = P.bw_items[ib + it];
+        const int item = bw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
         // entry (i, k), k >= i, of U11^{-1}: column k of the tall panel, or of the packed upper triangle
         int c1, tri;
-        const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
+        const gptr<double> p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
         const double* Xs = X + F.c0;
         double a[4];
 #pragma unroll
@@ -1958,8 +1974,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
           for (int u = 0; u < 4; u++) a[u] += l[u] * Xs[k + u];
         }
         for (; k < w; k++) a[0] += ldp(p + (c1 * k + tri * ((k * (k + 1)) >> 1))) * Xs[k];
-        const double* __restrict__ qv = fac + F.q_off + i;
-        const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+        const gptr<double> qv = fac + F.q_off + i;
+        const gptr<int32_t> idx = fidx + F.idx_off + w;
         k = 0;
         for (; k + 3 < ri; k += 4) {
           double l[4]; int id[4];
@@ -1973,7 +1989,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
       }
       __syncthreads();   // every read of this level's pivot values is done
       for (int it = tid; it < ni; it += 256) {
-        const int item = P.bw_items[ib + it];
+        const int item = bw_items[ib + it];
         X[LF[item >> 16].c0 + (item & 0xffff)] = Fv[it];
       }
     } else {
@@ -1981,11 +1997,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
       const int it = tid % RT, kg = tid / RT;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       if (it < ni) {
-        const int item = P.bw_items[ib + it];
+        const int item = bw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
         int c1, tri;
-        const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
+        const gptr<double> p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
         const double* Xs = X + F.c0;
         auto at = [&](int kk) { return ldp(p + (c1 * kk + tri * ((kk * (kk + 1)) >> 1))); };
         int k = i + kg;
@@ -1994,8 +2010,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
           a0 += l0 * Xs[k]; a1 += l1 * Xs[k + KG]; a2 += l2 * Xs[k + 2 * KG]; a3 += l3 * Xs[k + 3 * KG];
         }
         for (; k < w; k += KG) a0 += at(k) * Xs[k];
-        const double* __restrict__ qv = fac + F.q_off + i;
-        const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+        const gptr<double> qv = fac + F.q_off + i;
+        const gptr<int32_t> idx = fidx + F.idx_off + w;
         k = kg;
         for (; k + 3 * KG < ri; k += 4 * KG) {
           const double q0 = ldp(qv + (int64_t)w * k), q1 = ldp(qv + (int64_t)w * (k + KG)), q2 = ldp(qv + (int64_t)w * (k + 2 * KG)), q3 = ldp(qv + (int64_t)w * (k + 3 * KG));
@@ -2007,7 +2023,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
       R[kg * RT + it] = (a0 + a1) + (a2 + a3);
       __syncthreads();
       if (tid < ni) {
-        const int item = P.bw_items[ib + tid];
+        const int item = bw_items[ib + tid];
         double sum = 0.0;
         for (int g = 0; g < KG; g++) sum += R[g * RT + tid];
         X[LF[item >> 16].c0 + (item & 0xffff)] = sum;
@@ -2092,12 +2108,17 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
   for (int v = 0; v < NV; v++)
     for (int i = tid; i < nI; i += 256) X[v * nI + i] = xg[v * ldx + i];
   __syncthreads();
-  const double* __restrict__ fac = S.fac;
+  const gptr<double> fac = as_global(S.fac);            // (pointers out of structures: global memory, see as_global)
+  const gptr<int32_t> fw_items = as_global(P.fw_items), bw_items = as_global(P.bw_items), fidx = as_global(P.fidx),
+                      asm_ptr = as_global(P.asm_ptr), asm_src = as_global(P.asm_src), fw_ptr = as_global(P.fw_ptr), bw_ptr = as_global(P.bw_ptr);
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const gptr<v4i> fw_rec = (gptr<v4i>)P.fw_rec;
   // ---------------- forward
   for (int lev = 0; lev < P.nlev; lev++) {
-    const int ib = P.fw_ptr[lev], ni = P.fw_ptr[lev + 1] - ib;
+    const int ib = fw_ptr[lev], ni = fw_ptr[lev + 1] - ib;
     for (int it = tid; it < ni; it += 256) {
-      const FwRec rc = P.fw_rec[ib + it];
+      FwRec rc;
+      { const v4i q = fw_rec[ib + it]; __builtin_memcpy(&rc, &q, 16); }
       const int item = rc.item;
       const FusedFront& F = LF[item >> 16];
       const int r = item & 0xffff;
@@ -2109,7 +2130,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
 #pragma unroll
           for (int q = 0; q < 5; q++) if (q < rc.n) val += Cv[rc.s[q]];
         } else {
-          for (int t = P.asm_ptr[F.a_off + r]; t < P.asm_ptr[F.a_off + r + 1]; t++) val += Cv[P.asm_src[t]];
+          for (int t = asm_ptr[F.a_off + r]; t < asm_ptr[F.a_off + r + 1]; t++) val += Cv[asm_src[t]];
         }
         if (r < F.w) Fv[v * FS + F.lf_off + r] = val; else C[v * CS + F.c_off + r - F.w] = val;
       }
@@ -2117,11 +2138,11 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
     __syncthreads();
     if (ni > 128) {
       for (int it = tid; it < ni; it += 256) {
-        const int item = P.fw_items[ib + it];
+        const int item = fw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
         int c1, tri;
-        const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
+        const gptr<double> p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
         double a[4][NV];    // (the accumulation order of the single-vector kernel: bitwise the same column)
@@ -2157,11 +2178,11 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
 #pragma unroll
       for (int v = 0; v < NV; v++) { a0[v] = 0.0; a1[v] = 0.0; a2[v] = 0.0; a3[v] = 0.0; }
       if (it < ni) {
-        const int item = P.fw_items[ib + it];
+        const int item = fw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff, w = F.w;
         int c1, tri;
-        const double* __restrict__ p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
+        const gptr<double> p = lside(fac + F.lp_off, P.packed, r, w, F.ri, c1, tri);
         const double* f = Fv + F.lf_off;
         const int kmax = r < w ? r : w;
         auto at = [&](int kk) { return p[c1 * kk - tri * ((kk * (kk + 3)) >> 1)]; };
@@ -2184,7 +2205,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
       for (int v = 0; v < NV; v++) Fv[v * FS + 128 + kg * RT + it] = (a0[v] + a1[v]) + (a2[v] + a3[v]);
       __syncthreads();
       if (tid < ni) {
-        const int item = P.fw_items[ib + tid];
+        const int item = fw_items[ib + tid];
         const FusedFront& F = LF[item >> 16];
         const int r = item & 0xffff;
 #pragma unroll
@@ -2199,14 +2220,14 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
   }
   // ---------------- backward
   for (int lev = P.nlev - 1; lev >= 0; lev--) {
-    const int ib = P.bw_ptr[lev], ni = P.bw_ptr[lev + 1] - ib;
+    const int ib = bw_ptr[lev], ni = bw_ptr[lev + 1] - ib;
     if (ni > 128) {
       for (int it = tid; it < ni; it += 256) {
-        const int item = P.bw_items[ib + it];
+        const int item = bw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
         int c1, tri;
-        const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
+        const gptr<double> p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
         const double* Xs = X + F.c0;
         double a[4][NV];
 #pragma unroll
@@ -2228,8 +2249,8 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
 #pragma unroll
           for (int v = 0; v < NV; v++) a[0][v] += l * Xs[v * nI + k];
         }
-        const double* __restrict__ qv = fac + F.q_off + i;
-        const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+        const gptr<double> qv = fac + F.q_off + i;
+        const gptr<int32_t> idx = fidx + F.idx_off + w;
         k = 0;
         for (; k + 3 < ri; k += 4) {
           double l[4]; int id[4];
@@ -2250,7 +2271,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
       }
       __syncthreads();
       for (int it = tid; it < ni; it += 256) {
-        const int item = P.bw_items[ib + it];
+        const int item = bw_items[ib + it];
         const int dst = LF[item >> 16].c0 + (item & 0xffff);
 #pragma unroll
         for (int v = 0; v < NV; v++) X[v * nI + dst] = Fv[v * FS + it];
@@ -2262,11 +2283,11 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
 #pragma unroll
       for (int v = 0; v < NV; v++) { a0[v] = 0.0; a1[v] = 0.0; a2[v] = 0.0; a3[v] = 0.0; }
       if (it < ni) {
-        const int item = P.bw_items[ib + it];
+        const int item = bw_items[ib + it];
         const FusedFront& F = LF[item >> 16];
         const int i = item & 0xffff, w = F.w, ri = F.ri;
         int c1, tri;
-        const double* __restrict__ p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
+        const gptr<double> p = uside(fac + F.lp_off, P.packed, i, w, ri, c1, tri);
         const double* Xs = X + F.c0;
         auto at = [&](int kk) { return p[c1 * kk + tri * ((kk * (kk + 1)) >> 1)]; };
         int k = i + kg;
@@ -2283,8 +2304,8 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
 #pragma unroll
           for (int v = 0; v < NV; v++) a0[v] += l * Xs[v * nI + k];
         }
-        const double* __restrict__ qv = fac + F.q_off + i;
-        const int32_t* __restrict__ idx = P.fidx + F.idx_off + w;
+        const gptr<double> qv = fac + F.q_off + i;
+        const gptr<int32_t> idx = fidx + F.idx_off + w;
         k = kg;
         for (; k + 3 * KG < ri; k += 4 * KG) {
           const double q0 = qv[(int64_t)w * k], q1 = qv[(int64_t)w * (k + KG)], q2 = qv[(int64_t)w * (k + 2 * KG)], q3 = qv[(int64_t)w * (k + 3 * KG)];
@@ -2304,7 +2325,7 @@ __global__ void __launch_bounds__(256) k_interior_fused_mv(const FusedSub* __res
       for (int v = 0; v < NV; v++) Fv[v * FS + 128 + kg * RT + it] = (a0[v] + a1[v]) + (a2[v] + a3[v]);
       __syncthreads();
       if (tid < ni) {
-        const int item = P.bw_items[ib + tid];
+        const int item = bw_items[ib + tid];
         const int dst = LF[item >> 16].c0 + (item & 0xffff);
 #pragma unroll
         for (int v = 0; v < NV; v++) {
@@ -2360,10 +2381,10 @@ __global__ void __launch_bounds__(256) k_lvl_fwd_mv(const LvlTask* __restrict__ 
   const double* xb = x + S.xoff;
   double* yb = y + S.xoff;
   const int64_t cs = S.cstride;
-  double* cb = S.contrib + (int64_t)c0 * cs;   // contribution vectors of the columns c0 .. c0 + NV - 1 of the whole block
-  const int32_t* __restrict__ aptr = P->asm_ptr + F.a_off;
-  const int32_t* __restrict__ asrc = P->asm_src;
-  const double* __restrict__ Lp = S.fac + F.lp_off;
+  const gmptr<double> cb = as_global_rw(S.contrib) + (int64_t)c0 * cs;   // contribution vectors of the columns c0 .. c0 + NV - 1 of the whole block
+  const gptr<int32_t> aptr = as_global(P->asm_ptr) + F.a_off;
+  const gptr<int32_t> asrc = as_global(P->asm_src);
+  const gptr<double> Lp = as_global(S.fac) + F.lp_off;
   if (T.r0 < 0) {
     for (int j = tid; j < rows; j += 256) {
 #pragma unroll
@@ -2423,7 +2444,7 @@ __global__ void __launch_bounds__(256) k_lvl_fwd_mv(const LvlTask* __restrict__ 
   }
   __syncthreads();
   const int krow = i < rows ? (i < w ? i : w) : 0;
-  const double* __restrict__ Lr = Lp + (i < rows ? i : 0);
+  const gptr<double> Lr = Lp + (i < rows ? i : 0);
   const int chunk = ((kneed + 31) / 32) * 8;
   const int kb = g * chunk, ke = min(kb + chunk, kneed);
   double acc[8][NV];
@@ -2477,9 +2498,9 @@ __global__ void __launch_bounds__(256) k_lvl_bwd_mv(const LvlTask* __restrict__ 
   const int64_t ldp = w + ri;
   double* xb = x + S.xoff;
   const double* yb = y + S.xoff;
-  const int32_t* __restrict__ idx = P->fidx + F.idx_off + w;
-  const double* __restrict__ Lp = S.fac + F.lp_off;
-  const double* __restrict__ Q = S.fac + F.q_off;
+  const gptr<int32_t> idx = as_global(P->fidx) + F.idx_off + w;
+  const gptr<double> Lp = as_global(S.fac) + F.lp_off;
+  const gptr<double> Q = as_global(S.fac) + F.q_off;
   if (T.r0 < 0) {
     for (int k = tid; k < w + ri; k += 256) {
 #pragma unroll
@@ -2522,8 +2543,8 @@ __global__ void __launch_bounds__(256) k_lvl_bwd_mv(const LvlTask* __restrict__ 
   }
   __syncthreads();
   const int iv = i < w ? i : r0;
-  const double* __restrict__ Lr = Lp + iv + ldp * r0;
-  const double* __restrict__ Qr = Q + iv;
+  const gptr<double> Lr = Lp + iv + ldp * r0;
+  const gptr<double> Qr = Q + iv;
   const int chunk = ((total + 31) / 32) * 8;
   const int kb = g * chunk, ke = min(kb + chunk, total);
   double acc[8][NV];
@@ -3249,11 +3270,12 @@ __global__ void __launch_bounds__(64) k_blocks_apply_all(const BlkD* __restrict_
   extern __shared__ double xs[];
   const BlkD D = blocks[blockIdx.x];
   const int nb = D.nb;
-  for (int j = threadIdx.x; j < nb; j += 64) xs[j] = x[D.ids[j]];
+  const gptr<int32_t> ids = as_global(D.ids);          // (pointers out of the descriptor: global memory, see as_global)
+  for (int j = threadIdx.x; j < nb; j += 64) xs[j] = x[ids[j]];
   __syncthreads();
   const int i0 = D.r0 < 0 ? 0 : D.r0, i1 = D.r0 < 0 ? nb : min(nb, D.r0 + 64);
   for (int i = i0 + threadIdx.x; i < i1; i += 64) {
-    const double* __restrict__ M = D.binv + i;
+    const gptr<double> M = as_global(D.binv) + i;
     double a[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) a[u] = 0.0;
@@ -3266,7 +3288,7 @@ __global__ void __launch_bounds__(64) k_blocks_apply_all(const BlkD* __restrict_
       for (int u = 0; u < 8; u++) a[u] += l[u] * xs[j + u];
     }
     for (; j < nb; j++) a[0] += M[(int64_t)nb * j] * xs[j];
-    y[D.ids[i]] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    y[ids[i]] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
 }
 void blocks_apply_all(int32_t nblk, const BlkD* blocks, int32_t max_nb, const double* x, double* y) {
@@ -3288,15 +3310,16 @@ __global__ void __launch_bounds__(64) k_blocks_apply_all_mv(const BlkD* __restri
   extern __shared__ double xs[];   // [NV][XS]
   const BlkD D = blocks[blockIdx.x];
   const int nb = D.nb;
+  const gptr<int32_t> ids = as_global(D.ids);
   for (int j = threadIdx.x; j < nb; j += 64) {
-    const int id = D.ids[j];
+    const int id = ids[j];
 #pragma unroll
     for (int v = 0; v < NV; v++) xs[v * XS + j] = x[v * ldx + id];
   }
   __syncthreads();
   const int i0 = D.r0 < 0 ? 0 : D.r0, i1 = D.r0 < 0 ? nb : min(nb, D.r0 + 64);
   for (int i = i0 + threadIdx.x; i < i1; i += 64) {
-    const double* __restrict__ M = D.binv + i;
+    const gptr<double> M = as_global(D.binv) + i;
     double a[8][NV];
 #pragma unroll
     for (int u = 0; u < 8; u++)
@@ -3317,7 +3340,7 @@ __global__ void __launch_bounds__(64) k_blocks_apply_all_mv(const BlkD* __restri
 #pragma unroll
       for (int v = 0; v < NV; v++) a[0][v] += l * xs[v * XS + j];
     }
-    const int id = D.ids[i];
+    const int id = ids[i];
 #pragma unroll
     for (int v = 0; v < NV; v++) y[v * ldy + id] = ((a[0][v] + a[1][v]) + (a[2][v] + a[3][v])) + ((a[4][v] + a[5][v]) + (a[6][v] + a[7][v]));
   }

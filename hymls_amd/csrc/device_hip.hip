@@ -1258,9 +1258,9 @@ template <int KT>
 __global__ void __launch_bounds__(256) k_panel_fwd(PlanD P, BatchD B, const int32_t* __restrict__ list, const int64_t* __restrict__ poff,
                                                     int32_t count) {
   __shared__ double red[4][64];
-  // (measured and not kept, profiles/r03_f_ab_*: an XCD-aware renumbering that puts vertically adjacent tiles on one XCD
-  // so that they share the cache line they have in common -- FETCH_SIZE shows 1.25 x the panel bytes here -- made the
-  // phase slower: the tiles of the few largest fronts then all run on one XCD)
+  // (measured and not kept, profiles/r03_f_ab_*, r03_q_*: XCD-aware block orders meant to let the two workgroups that share
+  // a cache line -- vertically adjacent 64-row tiles; FETCH_SIZE shows 1.25 x the panel bytes here -- share an L2.  All
+  // consecutive tiles on one XCD: slower (the largest fronts land on one XCD); chunks of four, balanced: no difference)
   const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   const int q = bz % count, b = bz / count;
   const FrontD F = P.fronts[list[q]];

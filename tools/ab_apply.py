@@ -1,6 +1,8 @@
 """A/B of two builds of the library in ONE process on one GPU (development aid): both preconditioners are set up side by
 side (ctypes loads each .so with RTLD_LOCAL), then ApplyInverse alternates between them, so that clocks and
-temperature are the same for both.   python tools/ab_apply.py libA.so libB.so [N=256] [levels=2] [problem=Stokes]"""
+temperature are the same for both.   python tools/ab_apply.py libA.so libB.so [N=256] [levels=2] [problem=Stokes]
+Environment switches that a library reads when a handle is created can differ: AB_ENV_A="K=V,K2=V2" AB_ENV_B=...
+(two copies of one .so file give two independent instances)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +18,13 @@ prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": n, "ny": n, "n
        "Preconditioner": {"Separator Length": 8, "Number of Levels": levels, "Partitioner": "Skew Cartesian"}}
 P = []
 K = tv = None
-for path in libs:
+for q, path in enumerate(libs):
+    extra = dict(kv.split("=", 1) for kv in os.environ.get("AB_ENV_" + "AB"[q], "").split(",") if "=" in kv)
+    for k in list(os.environ):
+        if k.startswith("HYMLS_MI_AB_"):
+            del os.environ[k]
+    saved = {k: os.environ.get(k) for k in extra}
+    os.environ.update(extra)
     lib = hymls_amd.load_library(path)
     if K is None:
         K = hymls_amd.generate_problem(problem, n, n, n, re=1000.0, lib=lib)
@@ -25,7 +33,12 @@ for path in libs:
     p.Compute()
     p.set_profiling(True)
     P.append(p)
-    print("ready:", os.path.basename(path), p.level_sizes(), flush=True)
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    print("ready:", os.path.basename(path), extra, p.level_sizes(), flush=True)
 N = K[0].size - 1
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 b = torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 2 - 1

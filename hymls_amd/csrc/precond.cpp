@@ -14,9 +14,18 @@ namespace {
 
 struct Hasher {
   uint64_t h = 1469598103934665603ULL;
+  // 64 bits per step (the patterns of 70 k subdomains, ~100 kB each, are hashed at Initialize; equal hashes are confirmed by
+  // a full comparison afterwards)
   void add(const void* p, size_t n) {
     const unsigned char* c = (const unsigned char*)p;
-    for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ULL; }
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+      uint64_t w;
+      std::memcpy(&w, c + i, 8);
+      h = (h ^ w) * 0x9E3779B97F4A7C15ULL;
+      h ^= h >> 29;
+    }
+    for (; i < n; i++) { h ^= c[i]; h *= 1099511628211ULL; }
   }
   template <class T> void addv(const std::vector<T>& v) { size_t n = v.size(); add(&n, sizeof n); if (n) add(v.data(), n * sizeof(T)); }
 };
@@ -969,9 +978,13 @@ void LevelSolver::build_classes() {
   ivec sdl(cnt[nsep]), fill(cnt.begin(), cnt.end() - 1);
   for (int s = 0; s < nsd; s++)
     for (auto& g : hm_.sd[s].groups) for (int32_t x : g.nodes) { const int k = sidx(x); if (k >= 0) sdl[fill[k]++] = s; }
-  auto common = [&](int a, int b) {
-    int c = 0;
-    for (int i = cnt[a]; i < cnt[a + 1]; i++) for (int j = cnt[b]; j < cnt[b + 1]; j++) c += sdl[i] == sdl[j];
+  auto common = [&](int a, int b) {   // |L(a) and L(b)|: both lists ascend (filled in subdomain order)
+    int c = 0, i = cnt[a], j = cnt[b];
+    const int ie = cnt[a + 1], je = cnt[b + 1];
+    while (i < ie && j < je) {
+      const int x = sdl[i], y = sdl[j];
+      c += x == y; i += x <= y; j += y <= x;
+    }
     return c;
   };
   sep_sd_ptr_ = cnt; sep_sd_ = sdl;
@@ -987,7 +1000,11 @@ void LevelSolver::build_classes() {
   (void)n;
   // ---- pass 1: extended local pattern of every subdomain (in parallel, chunk by chunk), then classification
   struct SdPat { LocalPattern lp; ivec src, mult, lgptr, key_extra; uint64_t hash = 0; std::string err; };
+  static std::atomic<long long> tprof[6];
+  auto tnow = []() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto build_pattern = [&](int s, SdPat& out) {
+    long long tq = tnow();
+    auto lapq = [&](int k) { const long long t = tnow(); tprof[k] += t - tq; tq = t; };
     const Subdomain& S = hm_.sd[s];
     LocalPattern& lp = out.lp;
     lp.nI = (int32_t)S.interior.size();
@@ -1018,6 +1035,7 @@ void LevelSolver::build_classes() {
       while (hk[h] != -1) h = (h + 1) & (cap - 1);
       hk[h] = ext_rows[i]; hv[h] = i;
     }
+    lapq(0);
     lp.rowptr.assign(ne + 1, 0);
     lp.zero_diag.assign(lp.nI, 1);
     for (int i = 0; i < ne; i++) {
@@ -1039,6 +1057,7 @@ void LevelSolver::build_classes() {
       }
       lp.rowptr[i + 1] = (int32_t)lp.col.size();
     }
+    lapq(1);
     // relative coordinates
     lp.coord.resize(3 * (size_t)lp.nI);
     int32_t mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
@@ -1063,6 +1082,7 @@ void LevelSolver::build_classes() {
     H.addv(lp.rowptr); H.addv(lp.col); H.addv(lp.zero_diag); H.addv(lp.coord); H.addv(out.mult);
     H.addv(out.lgptr); H.addv(out.key_extra);
     out.hash = H.h;
+    lapq(2);
   };
   std::unordered_map<uint64_t, std::vector<int>> table;
   std::vector<ivec> sd_src(nsd);
@@ -1118,6 +1138,7 @@ void LevelSolver::build_classes() {
     }, 1);
     HYMLS_CHECK(mismatch == 0, -3, "two different subdomain patterns share one 64-bit hash");
   }
+  if (std::getenv("HYMLS_MI_PATTERN_PROF")) std::fprintf(stderr, "[hymls_mi] build_pattern thread-seconds: ext rows + table %.2f | K scan + find + mult %.2f | coords + hash %.2f\n", tprof[0] / 1e9, tprof[1] / 1e9, tprof[2] / 1e9);
   lap_bc("patterns + class lookup");
   for (size_t c = first_new; c < cls_.size(); c++) {
     Cls& C = *cls_[c];

@@ -28,6 +28,10 @@
 //     k_solve_transposed, k_dot  bordered systems
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <array>
+#include <map>
+#include <string>
+#include <cstdio>
 #include "device.hpp"
 
 namespace hymls {
@@ -207,6 +211,45 @@ void profile_collect(double* sum, int* cnt) {
 }
 
 static inline void launch_check() { HIP_CHECK(hipGetLastError()); }
+
+// HYMLS_MI_SETUP_PROF=1: the launches of the big-front path are timed one by one (events + a synchronisation per scope, so
+// the run itself is slower) and a table of shapes, time and rate goes to stderr when the library is unloaded
+// (tools/setup_prof.py reads it).
+struct SetupProf {
+  struct Row { double ms = 0, flop = 0; long calls = 0; };
+  std::map<std::pair<std::string, std::array<int, 5>>, Row> rows;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~SetupProf() {
+    for (auto& kv : rows)
+      std::fprintf(stderr, "SETUPPROF %s %d %d %d %d %d calls %ld ms %.4f tflops %.3f\n", kv.first.first.c_str(), kv.first.second[0],
+                   kv.first.second[1], kv.first.second[2], kv.first.second[3], kv.first.second[4], kv.second.calls, kv.second.ms,
+                   kv.second.ms > 0 ? kv.second.flop / (kv.second.ms * 1e9) : 0.0);
+  }
+  static SetupProf* get() {
+    static const bool on = std::getenv("HYMLS_MI_SETUP_PROF") && std::atoi(std::getenv("HYMLS_MI_SETUP_PROF")) > 0;
+    static SetupProf prof;
+    return on ? &prof : nullptr;
+  }
+  struct Scope {
+    SetupProf* p;
+    std::pair<std::string, std::array<int, 5>> key;
+    double flop;
+    Scope(const char* name, int a, int b, int c, int d, int e, double flop_ = 0) : p(get()), flop(flop_) {
+      if (!p) return;
+      key = {name, {a, b, c, d, e}};
+      if (!p->e0) { HIP_CHECK(hipEventCreate(&p->e0)); HIP_CHECK(hipEventCreate(&p->e1)); }
+      HIP_CHECK(hipEventRecord(p->e0, g_stream));
+    }
+    ~Scope() {
+      if (!p) return;
+      float ms = 0;
+      if (hipEventRecord(p->e1, g_stream) != hipSuccess || hipEventSynchronize(p->e1) != hipSuccess ||
+          hipEventElapsedTime(&ms, p->e0, p->e1) != hipSuccess) return;
+      Row& r = p->rows[key];
+      r.ms += ms; r.calls++; r.flop += flop;
+    }
+  };
+};
 
 // Pointers that reach a kernel inside a structure (plan tables, per-subdomain slabs) are generic to the compiler, which
 // then emits FLAT loads: they count on lgkmcnt as well as vmcnt and go through the LDS issue path, so every wait for an
@@ -1132,12 +1175,114 @@ __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_
         }
       }
 }
+// The same product with a 128 x 128 tile per workgroup: every wave owns a 64 x 64 quadrant = 4 x 4 MFMA tiles, so one K step
+// of four costs 8 LDS reads per lane for 16 matrix instructions (the 64 x 64 kernel above: 4 reads for 4 -- it is bound by
+// LDS bandwidth at half the matrix rate), and the next K slab travels from global memory to registers while the current one
+// is multiplied.  Rows of the LDS slabs are 144 doubles apart: the four groups of 16 lanes of a read (four K values) then
+// fall on two disjoint halves of the banks.  Every element of C receives exactly the sequence of matrix instructions the
+// 64 x 64 kernel gives it (K slabs of 16 in ascending order, four K values per instruction): the results are the same bits.
+constexpr int GB_LD = 144;
+template <int MODE, int MA, int MB>
+__global__ void __launch_bounds__(256, 2) k_gemm_f64_big(double* __restrict__ C, int64_t ldc, int64_t strideC,
+                                                       const double* __restrict__ A, int64_t lda, int64_t strideA,
+                                                       const double* __restrict__ Bm, int64_t ldb, int64_t strideB,
+                                                       int M, int N, int K) {
+  __shared__ double As[16 * GB_LD];
+  __shared__ double Bs[16 * GB_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  const int tm = blockIdx.x * 128, tn = blockIdx.y * 128;
+  C += (int64_t)blockIdx.z * strideC; A += (int64_t)blockIdx.z * strideA; Bm += (int64_t)blockIdx.z * strideB;
+  d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  int kbeg = 0, kend = K;
+  if (MA == 1) kend = min(K, tm + 128);
+  if (MA == 2) kbeg = max(0, (tm / 16) * 16);
+  if (MB == 1) kbeg = max(kbeg, (tn / 16) * 16);
+  if (MB == 2) kend = min(kend, tn + 128);
+  // this thread's share of a slab: A rows r = tid & 127 at k = (tid >> 7) + 2 t, B columns c = tid >> 1 at k = (tid & 1) * 8 + t
+  const int ar = tid & 127, ak = tid >> 7, bc = tid >> 1, bk = (tid & 1) * 8;
+  double ra[8], rb[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int gm = tm + ar, gk = k0 + ak + 2 * t;
+      double v = (gm < M && gk < K) ? A[gm + lda * gk] : 0.0;
+      if (MA == 1) v = gk > gm ? 0.0 : (gk == gm ? 1.0 : v);
+      if (MA == 2) v = gk < gm ? 0.0 : v;
+      ra[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int gn = tn + bc, gk = k0 + bk + t;
+      double v = (gn < N && gk < K) ? Bm[gk + ldb * gn] : 0.0;
+      if (MB == 1) v = gn > gk ? 0.0 : (gn == gk ? 1.0 : v);
+      if (MB == 2) v = gn < gk ? 0.0 : v;
+      rb[t] = v;
+    }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    __syncthreads();                                     // the previous slab has been read by every wave
+#pragma unroll
+    for (int t = 0; t < 8; t++) { As[(ak + 2 * t) * GB_LD + ar] = ra[t]; Bs[(bk + t) * GB_LD + bc] = rb[t]; }
+    __syncthreads();
+    if (k0 + 16 < kend) fetch(k0 + 16);                  // in flight during the products below
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 4) {
+      const int kk = ks + (lane >> 4);
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        a[q] = As[kk * GB_LD + wm + q * 16 + (lane & 15)];
+        b[q] = Bs[kk * GB_LD + wn + q * 16 + (lane & 15)];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p], b[q], acc[p][q], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gm = tm + wm + p * 16 + (lane >> 4) + 4 * r;
+        const int gn = tn + wn + q * 16 + (lane & 15);
+        if (gm < M && gn < N) {
+          if (MODE == 1) C[gm + ldc * gn] -= acc[p][q][r];
+          else if (MODE == 2) C[gm + ldc * gn] = -acc[p][q][r];
+          else C[gm + ldc * gn] = acc[p][q][r];
+        }
+      }
+}
+template <int MODE, int MA, int MB>
+static void gemm_f64_launch(double* C, int64_t ldc, int64_t sC, const double* A, int64_t lda, int64_t sA, const double* Bm, int64_t ldb,
+                            int64_t sB, int M, int N, int K, int batch);
 template <int MODE, int MA, int MB>
 static void gemm_f64(double* C, int64_t ldc, int64_t sC, const double* A, int64_t lda, int64_t sA, const double* Bm, int64_t ldb,
                      int64_t sB, int M, int N, int K, int batch) {
   if (M <= 0 || N <= 0 || batch <= 0) return;
-  hipLaunchKernelGGL((k_gemm_f64<MODE, MA, MB>), dim3((M + 63) / 64, (N + 63) / 64, batch), dim3(256), 0, g_stream, C, ldc, sC, A,
-                     lda, sA, Bm, ldb, sB, M, N, K);
+  SetupProf::Scope prof("gemm", MODE * 100 + MA * 10 + MB, M, N, K, batch, 2.0 * M * N * K * batch);
+  gemm_f64_launch<MODE, MA, MB>(C, ldc, sC, A, lda, sA, Bm, ldb, sB, M, N, K, batch);
+}
+template <int MODE, int MA, int MB>
+static void gemm_f64_launch(double* C, int64_t ldc, int64_t sC, const double* A, int64_t lda, int64_t sA, const double* Bm, int64_t ldb,
+                            int64_t sB, int M, int N, int K, int batch) {
+  // large products take the 128 x 128 tiles (HYMLS_MI_GEMM_TILE=64 keeps the small kernel everywhere: A/B measurements)
+  static const bool small_only = std::getenv("HYMLS_MI_GEMM_TILE") && std::atoi(std::getenv("HYMLS_MI_GEMM_TILE")) == 64;
+  if (!small_only && M > 96 && N > 96) {
+    hipLaunchKernelGGL((k_gemm_f64_big<MODE, MA, MB>), dim3((M + 127) / 128, (N + 127) / 128, batch), dim3(256), 0, g_stream, C, ldc, sC,
+                       A, lda, sA, Bm, ldb, sB, M, N, K);
+  } else {
+    hipLaunchKernelGGL((k_gemm_f64<MODE, MA, MB>), dim3((M + 63) / 64, (N + 63) / 64, batch), dim3(256), 0, g_stream, C, ldc, sC, A,
+                       lda, sA, Bm, ldb, sB, M, N, K);
+  }
   launch_check();
 }
 __global__ void k_big_root_update(PlanD P, BatchD B, FrontD F) {
@@ -1177,14 +1322,17 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
   double* A0 = B.scratch + F.f_off;
   double* slab = B.factor + (int64_t)b0 * P.factor_size + F.lp_off;
   double* Qs = B.factor + (int64_t)b0 * P.factor_size + F.q_off;
-  hipLaunchKernelGGL(k_big_zero, dim3(nblocks(mm, 256, 8192), nbc), dim3(256), 0, g_stream, A0, mm, P.scratch_size); launch_check();
+  { SetupProf::Scope prof("zero", m, 0, 0, 0, nbc);
+  hipLaunchKernelGGL(k_big_zero, dim3(nblocks(mm, 256, 8192), nbc), dim3(256), 0, g_stream, A0, mm, P.scratch_size); launch_check(); }
   if (F.ent_end > F.ent_begin) {
+    SetupProf::Scope prof("entries", m, 0, 0, 0, nbc);
     hipLaunchKernelGGL(k_big_entries, dim3(nblocks(F.ent_end - F.ent_begin, 256, 256), nbc), dim3(256), 0, g_stream, P, B, F, b0, kval);
     launch_check();
   }
   for (int c = 0; c < nkids; c++) {
     const int64_t rc = kids[c].ri + kids[c].rs;
     if (rc <= 0) continue;
+    SetupProf::Scope prof("extend_add", m, (int)rc, 0, 0, nbc);
     hipLaunchKernelGGL(k_big_extend_add, dim3(nblocks(rc * rc, 256, 8192), nbc), dim3(256), 0, g_stream, P, B, F, kids[c]);
     launch_check();
   }
@@ -1196,6 +1344,8 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     double* tk = B.tmp + (int64_t)k * 2 * PIECE * PIECE;
     static const bool scalar_pivot = std::getenv("HYMLS_MI_PIVOT_BLOCKED") && std::atoi(std::getenv("HYMLS_MI_PIVOT_BLOCKED")) == 0;   // (A/B switch)
     const int Wk = (wk + PB - 1) / PB * PB;
+    {
+    SetupProf::Scope prof("pivot", wk, 0, 0, 0, nbc, 4.0 / 3 * wk * wk * wk * nbc);
     // (measured, tools/pivot_check.hip: the blocked kernel wins unless the identity padding to a multiple of 32 is large)
     if (scalar_pivot || !(wk > 96 || (wk > 16 && Wk - wk < 24))) {
       hipLaunchKernelGGL(k_big_pivot, dim3(nbc), dim3(PIVOT_T), (size_t)(wk * wk + 2 * wk) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
@@ -1203,11 +1353,13 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
       hipLaunchKernelGGL(k_big_pivot_blk, dim3(nbc), dim3(PIVB_T), (size_t)(Wk * Wk + PIVB_LT * PB) * sizeof(double), g_stream, Ak, ld, sA, wk, slab + off * (lds + 1), lds, sS, tk, sT, B.flag);
     }
     launch_check();
+    }
     if (rk > 0) {
+      { SetupProf::Scope prof("trmm", wk, rk, 0, 0, nbc, 2.0 * wk * wk * rk * nbc);
       hipLaunchKernelGGL(k_big_trmm_u, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);
       launch_check();
       hipLaunchKernelGGL(k_big_trmm_l, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);
-      launch_check();
+      launch_check(); }
       gemm_f64<1, 0, 0>(Ak + wk + ld * wk, ld, sA, Ak + wk, ld, sA, Ak + ld * wk, ld, sA, rk, rk, wk, nbc);
     }
   }
@@ -1229,7 +1381,10 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     gemm_f64<0, 0, 1>(slab + w, lds, sS, A0 + w, ld, sA, slab, lds, sS, ri, w, w, nbc);
     gemm_f64<0, 2, 0>(Qs, w, sS, slab, lds, sS, A0 + ld * w, ld, sA, w, ri, w, nbc);
   }
-  if (F.parent < 0 && rs > 0) root_update(P, B, F, nbc);
+  if (F.parent < 0 && rs > 0) {
+    SetupProf::Scope prof("root_update", rs, 0, 0, 0, nbc);
+    root_update(P, B, F, nbc);
+  }
 }
 
 // ---- solves of the big fronts, all big fronts of one tree level per launch

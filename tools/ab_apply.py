@@ -31,6 +31,10 @@ for q, path in enumerate(libs):
         tv = hymls_amd.generate_testvector(*K, lib=lib)
     p = hymls_amd.Preconditioner(K, prm, testVector=tv, lib=lib)
     p.Compute()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    p.Compute()                       # numeric Compute with the pattern reused
+    torch.cuda.synchronize(); t_re = time.perf_counter() - t0
+    print("recompute %.3f s" % t_re, flush=True)
     p.set_profiling(True)
     P.append(p)
     for k, v in saved.items():

@@ -4,6 +4,7 @@
 // loops so that the index plans can be validated on a machine without a GPU.
 // Nothing in the product links the simulator.
 #pragma once
+#include <cstdio>
 #include "common.hpp"
 #include "symbolic.hpp"
 
@@ -42,6 +43,22 @@ inline int side_streams() {
 void fork_streams();
 void use_stream(int k);
 void join_streams();
+// named ranges for profilers: roctx ranges (`rocprofv3 --marker-trace`), labelled as the reference labels its timers,
+// "<class>_L<level>: <function>" (HYMLS_LPROF, reference src/HYMLS_Macros.hpp:86-137).  The roctx library is looked up at run
+// time (librocprofiler-sdk-roctx.so, then libroctx64.so); without it the calls do nothing.  HYMLS_MI_RANGE_LOG=<file>
+// additionally appends "push <label>" / "pop" lines to a file (tests).
+void range_push(const char* label);
+void range_pop();
+struct Range {
+  Range(const char* cls, int level, const char* fn) {
+    char buf[96];
+    std::snprintf(buf, sizeof buf, "%s_L%d: %s", cls, level, fn);
+    range_push(buf);
+  }
+  ~Range() { range_pop(); }
+  Range(const Range&) = delete;
+  Range& operator=(const Range&) = delete;
+};
 // event timing on the stream (seconds); ids are small integers
 void timer_start(int id);
 double timer_stop(int id);  // synchronises

@@ -28,6 +28,7 @@
 //     k_solve_transposed, k_dot  bordered systems
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <dlfcn.h>
 #include <array>
 #include <map>
 #include <string>
@@ -168,6 +169,35 @@ const double* zeros16() {
   return c.zeros;
 }
 size_t mem_free() { size_t f = 0, t = 0; HIP_CHECK(hipMemGetInfo(&f, &t)); return f; }
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  std::FILE* log = nullptr;
+  Roctx() {
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (push && pop) break;
+      push = nullptr; pop = nullptr;
+    }
+    if (const char* f = std::getenv("HYMLS_MI_RANGE_LOG")) log = std::fopen(f, "a");
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void range_push(const char* label) {
+  Roctx& r = roctx();
+  if (r.push) r.push(label);
+  if (r.log) { std::fprintf(r.log, "push %s\n", label); std::fflush(r.log); }
+}
+void range_pop() {
+  Roctx& r = roctx();
+  if (r.pop) r.pop();
+  if (r.log) { std::fprintf(r.log, "pop\n"); std::fflush(r.log); }
+}
 void timer_start(int id) {
   Context& c = ctx();
   if (!c.ev_init) {
@@ -1104,7 +1134,7 @@ __global__ void __launch_bounds__(256) k_big_trmm_l(double* __restrict__ A0, int
 // (f64 layout, cdna_hip_programming.md section 3).  MA / MB mask a triangular operand that is
 // stored packed with its sibling triangle: 1 = unit lower (above diagonal 0, diagonal 1),
 // 2 = upper (below diagonal 0).
-template <int MODE, int MA, int MB>
+template <int MODE, int MA, int MB, int VAR = 0>
 __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_t ldc, int64_t strideC,
                                                    const double* __restrict__ A, int64_t lda, int64_t strideA,
                                                    const double* __restrict__ Bm, int64_t ldb, int64_t strideB,
@@ -1157,7 +1187,9 @@ __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_
 #pragma unroll
       for (int p = 0; p < 2; p++)
 #pragma unroll
-        for (int q = 0; q < 2; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p], b[q], acc[p][q], 0, 0, 0);
+        for (int q = 0; q < 2; q++)
+          acc[p][q] = VAR == 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(a[p], b[q], acc[p][q], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f64_16x16x4f64(b[q], a[p], acc[p][q], 0, 0, 0);   // (transposed tile, see below)
     }
   }
 #pragma unroll
@@ -1166,8 +1198,8 @@ __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_
     for (int q = 0; q < 2; q++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int gm = tm + wm + p * 16 + (lane >> 4) + 4 * r;
-        const int gn = tn + wn + q * 16 + (lane & 15);
+        const int gm = tm + wm + p * 16 + (VAR == 0 ? (lane >> 4) + 4 * r : (lane & 15));
+        const int gn = tn + wn + q * 16 + (VAR == 0 ? (lane & 15) : (lane >> 4) + 4 * r);
         if (gm < M && gn < N) {
           if (MODE == 1) C[gm + ldc * gn] -= acc[p][q][r];   // (requesting the C tile before the K loop changed nothing: measured)
           else if (MODE == 2) C[gm + ldc * gn] = -acc[p][q][r];
@@ -1182,7 +1214,11 @@ __global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_
 // fall on two disjoint halves of the banks.  Every element of C receives exactly the sequence of matrix instructions the
 // 64 x 64 kernel gives it (K slabs of 16 in ascending order, four K values per instruction): the results are the same bits.
 constexpr int GB_LD = 144;
-template <int MODE, int MA, int MB>
+// VAR (development switch, tools/gemm_check.hip): 0 = C rows on lane >> 4 (a store touches 16 columns x 32 bytes),
+// 1 = operands exchanged in the matrix instruction, which computes the transposed tile: lane & 15 runs along the rows of C,
+// a load / store of C touches 4 columns x 128 contiguous bytes; 2 = 1 + the B slab fetched with K fastest (128 contiguous
+// bytes per column).  The sums are the same in all three (a b = b a exactly, same K order).
+template <int MODE, int MA, int MB, int VAR = 0>
 __global__ void __launch_bounds__(256, 2) k_gemm_f64_big(double* __restrict__ C, int64_t ldc, int64_t strideC,
                                                        const double* __restrict__ A, int64_t lda, int64_t strideA,
                                                        const double* __restrict__ Bm, int64_t ldb, int64_t strideB,
@@ -1203,8 +1239,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f64_big(double* __restrict__ C,
   if (MA == 2) kbeg = max(0, (tm / 16) * 16);
   if (MB == 1) kbeg = max(kbeg, (tn / 16) * 16);
   if (MB == 2) kend = min(kend, tn + 128);
-  // this thread's share of a slab: A rows r = tid & 127 at k = (tid >> 7) + 2 t, B columns c = tid >> 1 at k = (tid & 1) * 8 + t
-  const int ar = tid & 127, ak = tid >> 7, bc = tid >> 1, bk = (tid & 1) * 8;
+  // this thread's share of a slab: A rows r = tid & 127 at k = (tid >> 7) + 2 t; B columns c = tid >> 1 at k = (tid & 1) * 8 + t
+  // (VAR 2: B at k = tid & 15, columns c = (tid >> 4) + 16 t)
+  const int ar = tid & 127, ak = tid >> 7;
+  const int bc = VAR == 2 ? (tid >> 4) : (tid >> 1), bk = VAR == 2 ? (tid & 15) : (tid & 1) * 8;
   double ra[8], rb[8];
   auto fetch = [&](int k0) {
 #pragma unroll
@@ -1217,7 +1255,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f64_big(double* __restrict__ C,
     }
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-      const int gn = tn + bc, gk = k0 + bk + t;
+      const int gn = tn + bc + (VAR == 2 ? 16 * t : 0), gk = k0 + bk + (VAR == 2 ? 0 : t);
       double v = (gn < N && gk < K) ? Bm[gk + ldb * gn] : 0.0;
       if (MB == 1) v = gn > gk ? 0.0 : (gn == gk ? 1.0 : v);
       if (MB == 2) v = gn < gk ? 0.0 : v;
@@ -1228,7 +1266,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f64_big(double* __restrict__ C,
   for (int k0 = kbeg; k0 < kend; k0 += 16) {
     __syncthreads();                                     // the previous slab has been read by every wave
 #pragma unroll
-    for (int t = 0; t < 8; t++) { As[(ak + 2 * t) * GB_LD + ar] = ra[t]; Bs[(bk + t) * GB_LD + bc] = rb[t]; }
+    for (int t = 0; t < 8; t++) {
+      As[(ak + 2 * t) * GB_LD + ar] = ra[t];
+      if (VAR == 2) Bs[(bc + 16 * t) * 17 + bk] = rb[t];   // (column-major slab, 17 doubles apart: writes and reads without conflicts)
+      else Bs[(bk + t) * GB_LD + bc] = rb[t];
+    }
     __syncthreads();
     if (k0 + 16 < kend) fetch(k0 + 16);                  // in flight during the products below
 #pragma unroll
@@ -1238,12 +1280,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f64_big(double* __restrict__ C,
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         a[q] = As[kk * GB_LD + wm + q * 16 + (lane & 15)];
-        b[q] = Bs[kk * GB_LD + wn + q * 16 + (lane & 15)];
+        b[q] = VAR == 2 ? Bs[(wn + q * 16 + (lane & 15)) * 17 + kk] : Bs[kk * GB_LD + wn + q * 16 + (lane & 15)];
       }
 #pragma unroll
       for (int p = 0; p < 4; p++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p], b[q], acc[p][q], 0, 0, 0);
+        for (int q = 0; q < 4; q++)
+          acc[p][q] = VAR == 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(a[p], b[q], acc[p][q], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f64_16x16x4f64(b[q], a[p], acc[p][q], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -1252,8 +1296,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_f64_big(double* __restrict__ C,
     for (int q = 0; q < 4; q++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int gm = tm + wm + p * 16 + (lane >> 4) + 4 * r;
-        const int gn = tn + wn + q * 16 + (lane & 15);
+        const int gm = tm + wm + p * 16 + (VAR == 0 ? (lane >> 4) + 4 * r : (lane & 15));
+        const int gn = tn + wn + q * 16 + (VAR == 0 ? (lane & 15) : (lane >> 4) + 4 * r);
         if (gm < M && gn < N) {
           if (MODE == 1) C[gm + ldc * gn] -= acc[p][q][r];
           else if (MODE == 2) C[gm + ldc * gn] = -acc[p][q][r];
@@ -1274,13 +1318,18 @@ static void gemm_f64(double* C, int64_t ldc, int64_t sC, const double* A, int64_
 template <int MODE, int MA, int MB>
 static void gemm_f64_launch(double* C, int64_t ldc, int64_t sC, const double* A, int64_t lda, int64_t sA, const double* Bm, int64_t ldb,
                             int64_t sB, int M, int N, int K, int batch) {
-  // large products take the 128 x 128 tiles (HYMLS_MI_GEMM_TILE=64 keeps the small kernel everywhere: A/B measurements)
-  static const bool small_only = std::getenv("HYMLS_MI_GEMM_TILE") && std::atoi(std::getenv("HYMLS_MI_GEMM_TILE")) == 64;
-  if (!small_only && M > 96 && N > 96) {
-    hipLaunchKernelGGL((k_gemm_f64_big<MODE, MA, MB>), dim3((M + 127) / 128, (N + 127) / 128, batch), dim3(256), 0, g_stream, C, ldc, sC,
-                       A, lda, sA, Bm, ldb, sB, M, N, K);
+  // Tile choice, measured on the setup's shapes (tools/gemm_check.hip, profiles/r03_v_gemm_variants.txt): the 128 x 128 tiles win
+  // from K = 64 on when the launch fills the chip; thin updates (K = 32 .. 49 of the level-0 root fronts) are bound by the
+  // read-modify-write of C and run faster with four times as many, smaller workgroups.  Every variant gives the same bits.
+  // (HYMLS_MI_GEMM_TILE=64 / 128 forces one kernel: A/B measurements)
+  static const int forced = std::getenv("HYMLS_MI_GEMM_TILE") ? std::atoi(std::getenv("HYMLS_MI_GEMM_TILE")) : 0;
+  const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  const bool big = forced == 64 ? false : forced == 128 ? (M > 96 && N > 96) : (M > 96 && N > 96 && K >= 64 && tiles >= 768);
+  if (big) {
+    hipLaunchKernelGGL((k_gemm_f64_big<MODE, MA, MB, 2>), dim3((M + 127) / 128, (N + 127) / 128, batch), dim3(256), 0, g_stream, C, ldc,
+                       sC, A, lda, sA, Bm, ldb, sB, M, N, K);
   } else {
-    hipLaunchKernelGGL((k_gemm_f64<MODE, MA, MB>), dim3((M + 63) / 64, (N + 63) / 64, batch), dim3(256), 0, g_stream, C, ldc, sC, A,
+    hipLaunchKernelGGL((k_gemm_f64<MODE, MA, MB, 1>), dim3((M + 63) / 64, (N + 63) / 64, batch), dim3(256), 0, g_stream, C, ldc, sC, A,
                        lda, sA, Bm, ldb, sB, M, N, K);
   }
   launch_check();
@@ -1336,12 +1385,32 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     hipLaunchKernelGGL(k_big_extend_add, dim3(nblocks(rc * rc, 256, 8192), nbc), dim3(256), 0, g_stream, P, B, F, kids[c]);
     launch_check();
   }
-  // ---- blocked right-looking LU of the pivot block, in place, pieces of PIECE columns
+  // ---- blocked LU of the pivot block, in place, pieces of PIECE columns inside outer blocks of OUTER columns.  Inside an
+  // outer block the pieces are updated lazily (a piece's column and row panels receive the products of the block's earlier
+  // pieces just before the piece is factored), and everything beyond the outer block receives ONE update of rank OUTER:
+  // the read-modify-write of the trailing matrix, which bounds a rank-128 update at about a quarter of the matrix peak,
+  // is paid once per 512 columns (tools/gemm_check.hip: 3793 x 3793, rank 128 / 256 / 512 = 24 / 34 / 43 TFLOP/s).
+  // HYMLS_MI_OUTER_BLOCK=128 gives the plain right-looking order (A/B measurements).
+  static const int OUTER = [] {
+    const char* e = std::getenv("HYMLS_MI_OUTER_BLOCK");
+    const int v = e ? std::atoi(e) : 512;
+    return std::max(PIECE, v / PIECE * PIECE);
+  }();
   const int np = (w + PIECE - 1) / PIECE;
+  const int ppo = OUTER / PIECE;                       // pieces per outer block
   for (int k = 0; k < np; k++) {
     const int off = k * PIECE, wk = std::min(PIECE, w - off), rk = m - off - wk;
+    const int o0 = (k / ppo) * OUTER;                   // first column of this piece's outer block
+    const int o1 = std::min(w, o0 + OUTER);             // one past its last pivot column
     double* Ak = A0 + off * (ld + 1);
     double* tk = B.tmp + (int64_t)k * 2 * PIECE * PIECE;
+    if (off > o0) {
+      // products of the earlier pieces of this outer block: columns of this piece from its diagonal block down, then
+      // its rows to the right of the diagonal block
+      gemm_f64<1, 0, 0>(Ak, ld, sA, A0 + off + ld * o0, ld, sA, A0 + o0 + ld * off, ld, sA, m - off, wk, off - o0, nbc);
+      if (rk > 0)
+        gemm_f64<1, 0, 0>(Ak + ld * wk, ld, sA, A0 + off + ld * o0, ld, sA, A0 + o0 + ld * (off + wk), ld, sA, wk, rk, off - o0, nbc);
+    }
     static const bool scalar_pivot = std::getenv("HYMLS_MI_PIVOT_BLOCKED") && std::atoi(std::getenv("HYMLS_MI_PIVOT_BLOCKED")) == 0;   // (A/B switch)
     const int Wk = (wk + PB - 1) / PB * PB;
     {
@@ -1360,7 +1429,10 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
       launch_check();
       hipLaunchKernelGGL(k_big_trmm_l, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);
       launch_check(); }
-      gemm_f64<1, 0, 0>(Ak + wk + ld * wk, ld, sA, Ak + wk, ld, sA, Ak + ld * wk, ld, sA, rk, rk, wk, nbc);
+      // the last piece of an outer block: everything beyond the block, one update of rank o1 - o0
+      const int rt = m - o1;
+      if (off + wk == o1 && rt > 0)
+        gemm_f64<1, 0, 0>(A0 + o1 * (ld + 1), ld, sA, A0 + o1 + ld * o0, ld, sA, A0 + o0 + ld * o1, ld, sA, rt, rt, o1 - o0, nbc);
     }
   }
   // ---- explicit inverse of the whole pivot block (block columns / rows from the last to the first)

@@ -426,6 +426,8 @@ void DirectSolver::numeric(const dvec& val) {
 
 DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids, int64_t ngid,
                            const Params& cp, const ivec* clu_ptr, const ivec* clu, const ivec* clu_coord, bool border_pending) {
+  label_level_ = cp.level + 2;   // (cp: the parameters of the level above; the reference counts its levels from 1)
+  dev::Range range("CoarseSolver", label_level_, "Compute");
   ivec fix_rows;
   Csr A = prepare(A0, gids, fix_gids, cp, border_pending, fix_rows);
   n_ = A.n;
@@ -490,6 +492,7 @@ DirectSolver::DirectSolver(const Csr& A0, const ivec& gids, const ivec& fix_gids
 // reference's CoarseSolver keeps its Amesos solver across Compute calls in the same way, CoarseSolver.cpp:131-152.)
 bool DirectSolver::refactor(const Csr& A0, const ivec& gids, const ivec& fix_gids, const Params& cp, bool border_pending) {
   if (n_ == 0 || !lu_ || border_pending != border_pending_ || gids != pat_gids_ || fix_gids != pat_fix_) return false;
+  dev::Range range("CoarseSolver", label_level_, "Compute");
   const ivec tail_before = tail_z_;
   ivec fix_rows;
   Csr A = prepare(A0, gids, fix_gids, cp, border_pending, fix_rows);
@@ -508,6 +511,7 @@ void DirectSolver::solve(const double* b, double* x, bool zero_fixed) { solve_mv
 
 void DirectSolver::solve_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv, bool zero_fixed) {
   if (n_ == 0) return;
+  dev::Range range("CoarseSolver", label_level_, "ApplyInverse");
   if (nv > nv_alloc_) {
     dev::sync();
     dev::free(d_z_); dev::free(d_y_);
@@ -781,6 +785,7 @@ static double wall() {
 }
 
 void LevelSolver::initialize() {
+  dev::Range range("Preconditioner", level_ + 1, "Initialize");
   const bool dist = comm_->distributed();
   const bool verbose = std::getenv("HYMLS_MI_VERBOSE") != nullptr;
   double t0 = wall();
@@ -1706,6 +1711,7 @@ void LevelSolver::build_handoff(const ivec& next_owned) {
 
 void LevelSolver::compute() {
   HYMLS_CHECK(initialized_, -1, "level not initialized");
+  dev::Range range("Preconditioner", level_ + 1, "Compute");
   const bool verbose = std::getenv("HYMLS_MI_VERBOSE") != nullptr;
   double t0 = wall();
   auto lap = [&](const char* what) {
@@ -1729,6 +1735,8 @@ void LevelSolver::compute() {
   const int chunk_streams = level_ == 0 && !no_side ? std::max(0, std::min(chunk_streams_env, dev::side_streams())) : 0;
   struct MainStreamGuard { ~MainStreamGuard() { try { dev::use_stream(0); } catch (...) {} } } back_to_main;   // also when a launch throws
   for (auto& cp : cls_) dev::zero(cp->lu.batch.flag, 4 * sizeof(int32_t));   // (on the main stream, before any side stream starts)
+  // (the subdomain factorisations and what is kept of the Schur complement come out of the same launches here: one range)
+  auto range_mb = std::make_unique<dev::Range>("MatrixBlock", level_ + 1, "Compute");
   if (side || chunk_streams) dev::fork_streams();
   int64_t chunk_id = 0;
   // (coarser levels: classes in their order, round robin over the side streams.  Measured and not kept: classes in descending
@@ -1762,6 +1770,8 @@ void LevelSolver::compute() {
     }
   }
   if (side || chunk_streams) dev::join_streams();
+  range_mb.reset();
+  dev::Range range_sp("SchurPreconditioner", level_ + 1, "Compute");
   int32_t bad = 0, grown = 0;
   double growth = 0.0;
   for (auto& cp : cls_) { double g = 0.0; const int32_t f = cp->lu.check_flag(&g); bad |= (f & 1); grown |= (f & 2) >> 1; growth = std::max(growth, g); }
@@ -1794,6 +1804,7 @@ void LevelSolver::compute() {
     return;
   }
   dev::zero(d_flag_, sizeof(int32_t));
+  auto range_fb = std::make_unique<dev::Range>("SchurPreconditioner", level_ + 1, "factor blocks");
   for (auto& B : blocks_) {
     // block values = sum of the contributions of every adjacent subdomain, then LU + inverse
     // (Ifpack_DenseContainer::Compute -> dgetrf in the reference, SchurPreconditioner.cpp:284-291)
@@ -1829,6 +1840,7 @@ void LevelSolver::compute() {
   }
   int32_t flag = 0;
   dev::d2h(&flag, d_flag_, sizeof flag);
+  range_fb.reset();
   HYMLS_CHECK(comm_->allsum(flag != 0) == 0, -4,
               "singular separator block on level " + std::to_string(level_) +
                   " (3D Stokes-C needs the Skew Cartesian partitioner: isolated pressure 'tubes' on subdomain edges)");
@@ -1845,6 +1857,7 @@ void LevelSolver::compute() {
     }
   }
   lap("pull + separator blocks");
+  auto range_nl = std::make_unique<dev::Range>("SchurPreconditioner", level_ + 1, "ComputeNextLevel");
   const Csr& G = assemble_reduced(next_gids, &tvn);
   Csr& R = next_R_;
   drop_by_value(G, SMALL_ENTRY, 0, R);
@@ -1884,6 +1897,7 @@ void LevelSolver::interior_solve(double* x1) { interior_solve_mv(x1, n1_ + ngi_,
 
 // x1 <- A11^{-1} x1 for nv columns (leading dimension ld): the factor panels are streamed once per group of columns
 void LevelSolver::interior_solve_mv(double* x1, int64_t ld, int nv) {
+  dev::Range range("MatrixBlock", level_ + 1, "ApplyInverse");
   if (n_fsubs_ > 0) {
     if (nv == 1) dev::interior_solve_fused(n_fsubs_, d_fsubs_, d_fplans_, fused_lds_, x1);
     else dev::interior_solve_fused_mv(n_fsubs_, d_fsubs_, d_fplans_, fused_vec_lds_ + fused_front_lds_, fused_front_lds_, x1, ld, nv);
@@ -1926,6 +1940,7 @@ void LevelSolver::next_apply(const double* rhs, double* sol, int64_t ld, int nv)
 }
 
 void LevelSolver::schur_apply(double* rhs2, int64_t ldr, double* x2, int64_t ldx, int nv) {
+  dev::Range range("SchurPreconditioner", level_ + 1, "ApplyInverse");
   if (global_n2_ == 0) return;
   if (direct_schur_) {
     // (the direct solver of the whole Schur complement takes any leading dimensions)
@@ -1955,6 +1970,7 @@ void LevelSolver::apply_inverse(const double* b, double* x) { apply_inverse_mv(b
 // Preconditioner::ApplyInverse (reference src/HYMLS_Preconditioner.cpp:930-1070) for nv right-hand sides; the two
 // interior solves, the separator blocks and the coarser levels read their factors once per group of up to NV_MAX columns
 void LevelSolver::apply_inverse_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv) {
+  dev::Range range("Preconditioner", level_ + 1, "ApplyInverse");
   HYMLS_CHECK(next_ != nullptr || global_n2_ == 0, -1, "The preconditioner has not yet been computed.");
   ensure_nvec(nv);
   const int64_t ldz = n1_ + ngi_ + n2_, ld1 = std::max(n1_, 1), ld2 = std::max(n2_ + ngs_, 1);
@@ -2045,6 +2061,7 @@ void LevelSolver::build_matvec() {
 // (BorderedOperator interface of HYMLS::Preconditioner, reference src/HYMLS_Preconditioner.cpp:519-588,844-918,
 // 930-1070 and of the SchurPreconditioner, src/HYMLS_SchurPreconditioner.cpp:631-664,1517-1617)
 void LevelSolver::set_border(int m, const double* dV, const double* dW, const double* C) {
+  dev::Range range("Preconditioner", level_ + 1, "SetBorder");
   HYMLS_CHECK(initialized_, -1, "SetBorder needs an initialized preconditioner");
   void* ptrs[] = {d_bVu_, d_bWu_, d_bW1_, d_bQ1_, d_bSV_, d_bSW_, d_bNV_, d_bNW_, d_btmp_};
   for (void* q : ptrs) dev::free(q);
@@ -2185,6 +2202,7 @@ void LevelSolver::next_apply_bordered(const double* rhs, const double* T, double
 }
 
 void LevelSolver::schur_apply_bordered(double* rhs2, const double* q, double* x2, double* S) {
+  dev::Range range("SchurPreconditioner", level_ + 1, "ApplyInverse (bordered)");
   if (direct_schur_) { next_apply_bordered(rhs2, q, x2, S); return; }
   const int ng = (int)vs_.size(), m = bm_;
   dev::ot_apply(ng, d_gptr_, d_otw_, rhs2);
@@ -2201,6 +2219,7 @@ void LevelSolver::schur_apply_bordered(double* rhs2, const double* q, double* x2
 }
 
 void LevelSolver::apply_inverse_bordered(const double* b, const double* T, double* x, double* S) {
+  dev::Range range("Preconditioner", level_ + 1, "ApplyInverse (bordered)");
   if (bm_ == 0) { apply_inverse(b, x); return; }
   HYMLS_CHECK(next_ != nullptr, -1, "The preconditioner has not yet been computed.");
   const int m = bm_;
@@ -2226,6 +2245,7 @@ void LevelSolver::apply_inverse_bordered(const double* b, const double* T, doubl
 }
 
 void LevelSolver::matvec(const double* x, double* y) {
+  dev::Range range("MatrixBlock", level_ + 1, "Apply");
   if (!comm_->distributed()) { dev::spmv(K_.n, d_krow_, d_kcol_, d_kval_, x, y, 1.0, 0.0); return; }
   if (!mv_ready_) build_matvec();
   if (mv_stale_) { dev::gather(mv_nnz_, d_mv_src_, d_kval_, d_mv_val_); mv_stale_ = false; }   // new values since the last Compute

@@ -125,6 +125,7 @@ class DirectSolver : public Operator {
   std::vector<char> pat_zero_diag_;
   bool border_pending_ = false;
   int32_t n_ = 0;
+  int label_level_ = 1;   // level in the reference's numbering (labels of the profiler ranges)
   int nv_alloc_ = 0;
   // border: x = A^{-1} b - Z y, y = (C - W' Z)^{-1} (T - W' A^{-1} b), Z = A^{-1} V
   int bm_ = 0;

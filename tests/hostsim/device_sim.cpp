@@ -42,6 +42,13 @@ void* shared_scratch(size_t bytes) {
   return g_arena;
 }
 size_t mem_free() { return (size_t)1 << 40; }
+// ranges: no profiler on the host; the log file is what the tests read
+static std::FILE* range_log() {
+  static std::FILE* f = std::getenv("HYMLS_MI_RANGE_LOG") ? std::fopen(std::getenv("HYMLS_MI_RANGE_LOG"), "a") : nullptr;
+  return f;
+}
+void range_push(const char* label) { if (std::FILE* f = range_log()) { std::fprintf(f, "push %s\n", label); std::fflush(f); } }
+void range_pop() { if (std::FILE* f = range_log()) { std::fprintf(f, "pop\n"); std::fflush(f); } }
 static std::chrono::steady_clock::time_point t0[16];
 void timer_start(int id) { t0[id] = std::chrono::steady_clock::now(); }
 static std::vector<std::pair<int, std::chrono::steady_clock::time_point>> g_log;

@@ -22,8 +22,11 @@ open(os.path.join(out, "pmc_driver_maps.txt"), "w").write(open("/proc/self/maps"
 print("PMCDRIVER created", flush=True)
 P.Initialize()
 print("PMCDRIVER initialized", flush=True)
-P.Compute()
-print("PMCDRIVER computed", flush=True)
+import time
+for c in range(int(os.environ.get("PMC_DRIVER_COMPUTES", "1"))):
+    t0 = time.time()
+    P.Compute()
+    print("PMCDRIVER computed %d in %.3f s" % (c, time.time() - t0), flush=True)
 b = np.random.default_rng(0).uniform(-1, 1, rp.size - 1)
 for _ in range(napply):
     x = P.ApplyInverse(b)

@@ -1135,9 +1135,9 @@ __global__ void __launch_bounds__(256) k_big_trmm_l(double* __restrict__ A0, int
 // stored packed with its sibling triangle: 1 = unit lower (above diagonal 0, diagonal 1),
 // 2 = upper (below diagonal 0).
 template <int MODE, int MA, int MB, int VAR = 0>
-__global__ void __launch_bounds__(256) k_gemm_f64(double* __restrict__ C, int64_t ldc, int64_t strideC,
-                                                   const double* __restrict__ A, int64_t lda, int64_t strideA,
-                                                   const double* __restrict__ Bm, int64_t ldb, int64_t strideB,
+__global__ void __launch_bounds__(256) k_gemm_f64(double* C /* may alias an operand: panel_trmm */, int64_t ldc, int64_t strideC,
+                                                   const double* A, int64_t lda, int64_t strideA,
+                                                   const double* Bm, int64_t ldb, int64_t strideB,
                                                    int M, int N, int K) {
   __shared__ double As[16 * 64];
   __shared__ double Bs[16 * 64];
@@ -1219,9 +1219,9 @@ constexpr int GB_LD = 144;
 // a load / store of C touches 4 columns x 128 contiguous bytes; 2 = 1 + the B slab fetched with K fastest (128 contiguous
 // bytes per column).  The sums are the same in all three (a b = b a exactly, same K order).
 template <int MODE, int MA, int MB, int VAR = 0>
-__global__ void __launch_bounds__(256, 2) k_gemm_f64_big(double* __restrict__ C, int64_t ldc, int64_t strideC,
-                                                       const double* __restrict__ A, int64_t lda, int64_t strideA,
-                                                       const double* __restrict__ Bm, int64_t ldb, int64_t strideB,
+__global__ void __launch_bounds__(256, 2) k_gemm_f64_big(double* C /* may alias an operand: panel_trmm */, int64_t ldc, int64_t strideC,
+                                                       const double* A, int64_t lda, int64_t strideA,
+                                                       const double* Bm, int64_t ldb, int64_t strideB,
                                                        int M, int N, int K) {
   __shared__ double As[16 * GB_LD];
   __shared__ double Bs[16 * GB_LD];
@@ -1319,12 +1319,12 @@ template <int MODE, int MA, int MB>
 static void gemm_f64_launch(double* C, int64_t ldc, int64_t sC, const double* A, int64_t lda, int64_t sA, const double* Bm, int64_t ldb,
                             int64_t sB, int M, int N, int K, int batch) {
   // Tile choice, measured on the setup's shapes (tools/gemm_check.hip, profiles/r03_v_gemm_variants.txt): the 128 x 128 tiles win
-  // from K = 64 on when the launch fills the chip; thin updates (K = 32 .. 49 of the level-0 root fronts) are bound by the
+  // from K = 256 on, and from K = 64 on when the launch fills the chip; thin updates (K = 32 .. 49 of the level-0 root fronts) are bound by the
   // read-modify-write of C and run faster with four times as many, smaller workgroups.  Every variant gives the same bits.
   // (HYMLS_MI_GEMM_TILE=64 / 128 forces one kernel: A/B measurements)
   static const int forced = std::getenv("HYMLS_MI_GEMM_TILE") ? std::atoi(std::getenv("HYMLS_MI_GEMM_TILE")) : 0;
   const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
-  const bool big = forced == 64 ? false : forced == 128 ? (M > 96 && N > 96) : (M > 96 && N > 96 && K >= 64 && tiles >= 768);
+  const bool big = forced == 64 ? false : forced == 128 ? (M > 96 && N > 96) : (M > 96 && N > 96 && (K >= 256 || (K >= 64 && tiles >= 768)));
   if (big) {
     hipLaunchKernelGGL((k_gemm_f64_big<MODE, MA, MB, 2>), dim3((M + 127) / 128, (N + 127) / 128, batch), dim3(256), 0, g_stream, C, ldc,
                        sC, A, lda, sA, Bm, ldb, sB, M, N, K);
@@ -1333,6 +1333,28 @@ static void gemm_f64_launch(double* C, int64_t ldc, int64_t sC, const double* A,
                        lda, sA, Bm, ldb, sB, M, N, K);
   }
   launch_check();
+}
+// The panels of a pivot piece on the matrix cores, IN PLACE: U12 = L^{-1} F12 (wk x rk, right of the piece) and L21 = F21 U^{-1}
+// (rk x wk, below it), with the piece's explicit triangular inverses from the pivot kernel.  In place is safe because one
+// workgroup owns everything it reads of the panel: its tile spans all wk <= 128 rows (columns) of the panel, the K loop has
+// taken the whole operand in before the first store, and no other workgroup reads that tile.  (Before: k_big_trmm_u / _l,
+// one thread per entry with a dot product from global memory, 1.8 TFLOP/s, 11 % of the recompute's kernel time.)
+static void panel_trmm(double* Ak, int64_t ld, int64_t sA, const double* tk, int64_t sT, int wk, int rk, int nbc) {
+  const double* Lf = tk;
+  const double* Uf = tk + (int64_t)PIECE * PIECE;
+  double* U12 = Ak + ld * wk;
+  double* L21 = Ak + wk;
+  if (wk <= 64) {
+    hipLaunchKernelGGL((k_gemm_f64<0, 0, 0, 1>), dim3(1, (rk + 63) / 64, nbc), dim3(256), 0, g_stream, U12, ld, sA, Lf, (int64_t)wk, sT, U12, ld, sA, wk, rk, wk);
+    launch_check();
+    hipLaunchKernelGGL((k_gemm_f64<0, 0, 0, 1>), dim3((rk + 63) / 64, 1, nbc), dim3(256), 0, g_stream, L21, ld, sA, L21, ld, sA, Uf, (int64_t)wk, sT, rk, wk, wk);
+    launch_check();
+  } else {
+    hipLaunchKernelGGL((k_gemm_f64_big<0, 0, 0, 2>), dim3(1, (rk + 127) / 128, nbc), dim3(256), 0, g_stream, U12, ld, sA, Lf, (int64_t)wk, sT, U12, ld, sA, wk, rk, wk);
+    launch_check();
+    hipLaunchKernelGGL((k_gemm_f64_big<0, 0, 0, 2>), dim3((rk + 127) / 128, 1, nbc), dim3(256), 0, g_stream, L21, ld, sA, L21, ld, sA, Uf, (int64_t)wk, sT, rk, wk, wk);
+    launch_check();
+  }
 }
 __global__ void k_big_root_update(PlanD P, BatchD B, FrontD F) {
   const int slot = blockIdx.y;
@@ -1425,10 +1447,13 @@ void factor_big_front(const PlanD& P, const BatchD& B, const FrontD& F, const Fr
     }
     if (rk > 0) {
       { SetupProf::Scope prof("trmm", wk, rk, 0, 0, nbc, 2.0 * wk * wk * rk * nbc);
+      static const bool scalar_trmm = std::getenv("HYMLS_MI_TRMM_SCALAR") != nullptr;   // (A/B switch)
+      if (!scalar_trmm) panel_trmm(Ak, ld, sA, tk, sT, wk, rk, nbc);
+      else {
       hipLaunchKernelGGL(k_big_trmm_u, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);
       launch_check();
       hipLaunchKernelGGL(k_big_trmm_l, dim3((rk + 7) / 8, nbc), dim3(256), (size_t)wk * 8 * sizeof(double), g_stream, Ak, ld, sA, wk, rk, tk, sT);
-      launch_check(); }
+      launch_check(); } }
       // the last piece of an outer block: everything beyond the block, one update of rank o1 - o0
       const int rt = m - o1;
       if (off + wk == o1 && rt > 0)

@@ -338,6 +338,13 @@ void MergedSolve::build(const std::vector<std::pair<int32_t, const BatchedLU*>>&
     }
     fw_off.push_back((int32_t)tf.size()); bw_off.push_back((int32_t)tb.size());
     fw_lds.push_back(lf); bw_lds.push_back(lb);
+    if (std::getenv("HYMLS_MI_VERBOSE")) {
+      int64_t cf = 0, cbk = 0, mf = 0, mb = 0;
+      for (auto& t : fw[l]) { cf += t.first; mf = std::max(mf, t.first); }
+      for (auto& t : bw[l]) { cbk += t.first; mb = std::max(mb, t.first); }
+      std::fprintf(stderr, "[hymls_mi] merged solve tree level %zu: forward %zu tasks %.1f MB (largest %.2f MB), backward %zu tasks %.1f MB (largest %.2f MB)\n",
+                   l, fw[l].size(), 8e-6 * cf, 8e-6 * mf, bw[l].size(), 8e-6 * cbk, 8e-6 * mb);
+    }
   }
   d_subs = dev::upload(lsubs);
   d_fw = dev::upload(tf); d_bw = dev::upload(tb);

@@ -791,6 +791,19 @@ static double wall() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// HYMLS_MI_VERBOSE=2: wall time of the steps inside the phases of Initialize (host work; development aid)
+struct FineLap {
+  double t;
+  bool on;
+  FineLap() : t(wall()), on(std::getenv("HYMLS_MI_VERBOSE") && std::atoi(std::getenv("HYMLS_MI_VERBOSE")) >= 2) {}
+  void operator()(const char* what) {
+    if (!on) return;
+    const double n = wall();
+    std::fprintf(stderr, "[hymls_mi]       . %-40s %.3f s\n", what, n - t);
+    t = n;
+  }
+};
+
 void LevelSolver::initialize() {
   dev::Range range("Preconditioner", level_ + 1, "Initialize");
   const bool dist = comm_->distributed();
@@ -804,6 +817,7 @@ void LevelSolver::initialize() {
   else { ivec lg(gids_.begin(), gids_.begin() + nrows_); partition(&lg); }
   lap("partition");
   if (dist) localize();
+  FineLap fine;
   const int n = K_.n;
   HYMLS_CHECK((int)gids_.size() == n && (int)tv_.size() == n, -2, "level: inconsistent sizes");
   g2l_.assign(ngid_, -1);
@@ -814,6 +828,7 @@ void LevelSolver::initialize() {
   intidx_.assign(n, -1);
   sep_row_.clear();
   gptr_.assign(1, 0);
+  fine("g2l, pos2, intidx tables");
   {
     // group pointers first (sequential, one entry per owned group), then the nodes of every subdomain in parallel
     std::vector<int64_t> g0(my_sds_.size() + 1, 0);
@@ -873,6 +888,7 @@ void LevelSolver::initialize() {
   lap("separator numbering");
   build_classes();
   lap("pattern classes + plans");
+  fine.t = wall();
   // owned rows = layout of the vectors handed to apply_inverse (order of the rows as they were given)
   {
     ivec user(n, -1);
@@ -885,6 +901,7 @@ void LevelSolver::initialize() {
     global_n_ = comm_->allsum(n1_ + n2_);
     global_n2_ = comm_->allsum(n2_);
   }
+  fine("owned rows / user order");
   // A12 (interior rows x separators incl. ghosts) / A21 (owned separator rows x interiors incl. ghosts)
   ivec node_sd;     // local node -> halo subdomain holding it as interior
   if (dist) {
@@ -894,6 +911,7 @@ void LevelSolver::initialize() {
   ivec row_of_internal(n1_);
   for (int i = 0; i < n; i++) if (intidx_[i] >= 0) row_of_internal[intidx_[i]] = i;
   a12_row_.assign(n1_ + 1, 0); a21_row_.assign(n2_ + 1, 0);
+  fine("row_of_internal");
   // A12: count, prefix, fill (rows in parallel)
   parallel_for(n1_, [&](int64_t t) {
     const int r = row_of_internal[t];
@@ -911,6 +929,7 @@ void LevelSolver::initialize() {
       if (pos2_[c] >= 0) { a12_col_[o] = pos2_[c]; a12_src_[o] = e; o++; }
     }
   });
+  fine("A12 count / prefix / fill");
   // A21: ghost interior columns are numbered first (sequential over the few boundary rows), then count / fill
   std::vector<std::vector<int64_t>> want_int(comm_->size);
   std::vector<ivec> dst_int(comm_->size);
@@ -951,6 +970,7 @@ void LevelSolver::initialize() {
     xch_int_.build(*comm_, want_int, dst_int, [&](int64_t g) { const int l = g2l_[g]; return l >= 0 ? intidx_[l] : -1; });
     xch_sep_.build(*comm_, want_sep, dst_sep, [&](int64_t g) { const int l = g2l_[g]; return (l >= 0 && pos2_[l] < n2_) ? pos2_[l] : -1; });
   }
+  fine("A21 count / prefix / fill + halo plans");
   lap("A12/A21 + halo plans");
   build_schur_setup();
   lap("Schur setup + uploads");
@@ -999,7 +1019,9 @@ void LevelSolver::build_classes() {
     }
     return c;
   };
+  FineLap fine;
   sep_sd_ptr_ = cnt; sep_sd_ = sdl;
+  fine("(classes) subdomains listing each separator node");
   sd_center_.assign(3 * (size_t)nsd, 0);
   for (int s = 0; s < nsd; s++) {
     int64_t acc[3] = {0, 0, 0}, m = 0;
@@ -1009,6 +1031,7 @@ void LevelSolver::build_classes() {
     for (int a = 0; a < 3; a++) sd_center_[3 * (size_t)s + a] = m ? (int32_t)(acc[a] / m) : 0;
   }
   sd_xoff_.assign(nsd, 0); sd_cls_.assign(nsd, -1); sd_bidx_.assign(nsd, -1);
+  fine("(classes) subdomain centres");
   (void)n;
   // ---- pass 1: extended local pattern of every subdomain (in parallel, chunk by chunk), then classification
   struct SdPat { LocalPattern lp; ivec src, mult, lgptr, key_extra; uint64_t hash = 0; std::string err; };
@@ -1273,6 +1296,7 @@ void LevelSolver::build_schur_setup() {
   }
   auto owned_sep = [&](int32_t gid) { const int l = g2l_[gid]; return (l >= 0 && pos2_[l] >= 0 && pos2_[l] < n2_) ? pos2_[l] : -1; };
   lap("kept entries");
+  FineLap fine;
   // ---- records of the neighbours' subdomains that touch separators owned here
   std::vector<std::pair<int, int64_t>> contributors;   // (subdomain, base of its record in the extraction buffer)
   for (int s : my_sds_) contributors.emplace_back(s, cls_[sd_cls_[s]]->ext_base + (int64_t)sd_bidx_[s] * cls_[sd_cls_[s]]->ext_size);
@@ -1343,6 +1367,7 @@ void LevelSolver::build_schur_setup() {
   ivec ct_vg;
   std::vector<std::vector<BlkContrib>> ct_blk;
   for (pass = 0; pass < 2; pass++) {
+  fine(pass == 0 ? "(contributions) contributor list" : "(contributions) pass 0 incl. blocks");
   if (pass == 1) {
     for (int64_t r = 0; r < red_.n; r++) rcount[r + 1] += rcount[r];
     keys.resize((size_t)rcount[red_.n]);
@@ -1455,6 +1480,7 @@ void LevelSolver::build_schur_setup() {
     }
   }
   }  // passes
+  fine("(contributions) pass 1 (key fill)");
   if (!direct_schur_) {
     for (size_t c = 0; c < blocks_.size(); c++) {
       BlockClass& B = blocks_[c];
@@ -1491,6 +1517,7 @@ void LevelSolver::build_schur_setup() {
     d_vrhs_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
     d_vsol_ = (double*)dev::alloc((size_t)std::max(ng_owned, 1) * sizeof(double));
   }
+  fine("(contributions) block tables + uploads");
   lap("contributions");
   // buckets -> CSR pattern (columns = gids) with pull lists: sort every row (column gid, then source position)
   const int64_t nr = red_.n;
@@ -1501,6 +1528,7 @@ void LevelSolver::build_schur_setup() {
     for (int64_t k = rcount[r]; k < rcount[r + 1]; k++) nu += k == rcount[r] || (keys[k] >> 33) != (keys[k - 1] >> 33);
     red_.rowptr[r + 1] = nu;
   });
+  fine("(pull lists) row sorts");
   for (int64_t r = 0; r < nr; r++) red_.rowptr[r + 1] += red_.rowptr[r];
   red_.col.assign((size_t)red_.rowptr[nr], 0);
   red_pull_ptr_.assign((size_t)red_.rowptr[nr] + 1, 0);
@@ -1513,6 +1541,9 @@ void LevelSolver::build_schur_setup() {
       red_pull_ptr_[e + 1] = k + 1;
     }
   });
+  fine("(pull lists) columns + pull pointers");
+  if (fine.on) std::fprintf(stderr, "[hymls_mi]       . reduced matrix: %lld rows, %lld entries, %lld pulls; extraction buffer %lld doubles\n", (long long)nr,
+                            (long long)red_.col.size(), (long long)keys.size(), (long long)ext_total_);
   { std::vector<uint64_t>().swap(keys); }
   red_.val.assign(red_.col.size(), 0.0);
   d_red_pull_ptr_ = dev::upload(red_pull_ptr_); d_red_pull_idx_ = dev::upload(red_pull_idx_);
@@ -1536,6 +1567,7 @@ void LevelSolver::build_schur_setup() {
       C.d_glink = dev::upload(glink); C.d_goff = dev::upload(goff); C.d_lblen = dev::upload(lblen); C.d_lboff = dev::upload(lboff);
     }
   }
+  fine("(pull lists) uploads + allocations");
   lap("pull lists");
   // ---- tables of the fused interior solve (classes whose vectors fit in LDS)
   constexpr int32_t LDS_CAP = 12288;  // doubles (96 KiB)

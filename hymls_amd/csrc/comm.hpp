@@ -54,19 +54,19 @@ struct Comm {
     return in;
   }
   // concatenation over ranks (rank order) of `mine`; counts[q] = contribution of rank q
-  template <class T>
-  std::vector<T> allgather(const std::vector<T>& mine, std::vector<int64_t>* counts = nullptr) const {
+  template <class T, class A>
+  std::vector<T, A> allgather(const std::vector<T, A>& mine, std::vector<int64_t>* counts = nullptr) const {
     if (!distributed()) { if (counts) counts->assign(1, (int64_t)mine.size()); return mine; }
     // all-to-all with the same segment for every peer: the receive buffer IS the concatenation in rank order
     std::vector<int64_t> sc(size, (int64_t)mine.size());
     std::vector<int64_t> rc = exchange_counts(sc);
     int64_t nr = 0;
     for (int64_t c : rc) nr += c;
-    std::vector<T> sbuf;
+    std::vector<T, A> sbuf;
     sbuf.reserve(std::max<size_t>(1, mine.size() * (size_t)size));
     for (int q = 0; q < size; q++) sbuf.insert(sbuf.end(), mine.begin(), mine.end());
     if (sbuf.empty()) sbuf.resize(1);
-    std::vector<T> all((size_t)std::max<int64_t>(nr, 1));
+    std::vector<T, A> all((size_t)std::max<int64_t>(nr, 1));
     a2a_host(sbuf.data(), sc, all.data(), rc, (int)sizeof(T));
     all.resize((size_t)nr);
     if (counts) *counts = rc;

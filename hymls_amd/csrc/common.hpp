@@ -10,6 +10,7 @@
 #include <numeric>
 #include <cmath>
 #include <thread>
+#include <memory>
 #include <mutex>
 #include <exception>
 
@@ -31,12 +32,26 @@ struct Error : std::runtime_error {
 
 using ivec = std::vector<int32_t>;
 using dvec = std::vector<double>;
+// vectors of plain numbers whose resize() leaves the new entries uninitialised: for the gigabyte-sized tables of the setup
+// that are filled in parallel right after (a value-initialising resize is a serial memset: 10 GB of it at 256^3)
+template <class T>
+struct no_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { using other = no_init_allocator<U>; };
+  no_init_allocator() = default;
+  template <class U> no_init_allocator(const no_init_allocator<U>&) {}
+  template <class U> void construct(U* p) { ::new ((void*)p) U; }
+  template <class U, class A0, class... A> void construct(U* p, A0&& a0, A&&... a) { ::new ((void*)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+template <class T> using rawvec = std::vector<T, no_init_allocator<T>>;
+using cvec = rawvec<int32_t>;   // column indices of a Csr
+using vvec = rawvec<double>;    // values of a Csr
 
 // host CSR matrix with an explicit gid per local row/col (square, same map)
 struct Csr {
   int32_t n = 0;
-  ivec rowptr, col;  // local column indices
-  dvec val;
+  ivec rowptr;
+  cvec col;  // local column indices (resize() does not initialise: filled by whoever sizes it)
+  vvec val;
   int64_t nnz() const { return (int64_t)col.size(); }
 };
 
@@ -93,6 +108,44 @@ void parallel_for(int64_t n, Fn fn, int64_t grain = 256) {
     });
   for (auto& x : th) x.join();
   if (err) std::rethrow_exception(err);
+}
+
+// in-place inclusive prefix sum of a[0 .. n) on the setup threads (chunk sums, their serial scan, offsets added in parallel)
+template <class T>
+void parallel_inclusive_scan(T* a, int64_t n) {
+  constexpr int64_t CH = 1 << 20;
+  if (n < 4 * CH) { for (int64_t i = 1; i < n; i++) a[i] += a[i - 1]; return; }
+  const int64_t nc = (n + CH - 1) / CH;
+  std::vector<T> sum((size_t)nc);
+  parallel_for(nc, [&](int64_t c) {
+    const int64_t e = std::min(n, (c + 1) * CH);
+    for (int64_t i = c * CH + 1; i < e; i++) a[i] += a[i - 1];
+    sum[(size_t)c] = a[e - 1];
+  }, 1);
+  for (int64_t c = 1; c < nc; c++) sum[(size_t)c] += sum[(size_t)c - 1];
+  parallel_for(nc - 1, [&](int64_t c) {
+    const T off = sum[(size_t)c];
+    const int64_t e = std::min(n, (c + 2) * CH);
+    for (int64_t i = (c + 1) * CH; i < e; i++) a[i] += off;
+  }, 1);
+}
+// stream compaction in index order: emit(i, position among the kept) for every i in [0, n) with keep(i); returns the count
+template <class Keep, class Emit>
+int64_t parallel_compact(int64_t n, Keep keep, Emit emit) {
+  constexpr int64_t CH = 1 << 20;
+  const int64_t nc = std::max<int64_t>(1, (n + CH - 1) / CH);
+  std::vector<int64_t> cnt((size_t)nc + 1, 0);
+  parallel_for(nc, [&](int64_t c) {
+    int64_t k = 0;
+    for (int64_t i = c * CH, e = std::min(n, (c + 1) * CH); i < e; i++) k += keep(i) ? 1 : 0;
+    cnt[(size_t)c + 1] = k;
+  }, 1);
+  for (int64_t c = 0; c < nc; c++) cnt[(size_t)c + 1] += cnt[(size_t)c];
+  parallel_for(nc, [&](int64_t c) {
+    int64_t k = cnt[(size_t)c];
+    for (int64_t i = c * CH, e = std::min(n, (c + 1) * CH); i < e; i++) if (keep(i)) emit(i, k++);
+  }, 1);
+  return cnt[(size_t)nc];
 }
 
 }  // namespace hymls

@@ -68,8 +68,8 @@ double timer_stop(int id);  // synchronises
 void mark(int phase, bool begin);
 void profile_collect(double* sum, int* cnt);
 
-template <class T>
-T* upload(const std::vector<T>& v) {
+template <class T, class A>
+T* upload(const std::vector<T, A>& v) {
   T* p = (T*)alloc(std::max<size_t>(v.size(), 1) * sizeof(T));
   if (!v.empty()) h2d(p, v.data(), v.size() * sizeof(T));
   return p;
@@ -139,6 +139,10 @@ void spmv(int32_t nrows, const int32_t* rowptr, const int32_t* col, const double
           const double* x, double* y, double alpha, double beta, int64_t nnz_hint = -1);
 // out[e] = sum_{t in [ptr[e],ptr[e+1])} in[idx[t]]   (deterministic pull-assembly)
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out);
+// pull tables of the reduced matrix from its sorted keys (column gid << 33 | source position), rows [rcount[r], rcount[r+1])
+// of the key array, entries [rowptr[r], rowptr[r+1]) of the matrix: idx[k] = source of key k, ptr[e] .. ptr[e+1] = the keys
+// of entry e (a run of equal column gids)
+void build_pull_tables(int64_t nrows, const int64_t* rcount, const int32_t* rowptr, const uint64_t* keys, int64_t* ptr, int64_t* idx);
 // out[B*blen + k] = sum_{t in [ptr[B],ptr[B+1])} in[base[t] + k], k < blen  (whole dense blocks)
 void pull_sum_blocks(int64_t blen, int32_t nblk, const int64_t* ptr, const int64_t* base,
                      const double* in, double* out);

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <dlfcn.h>
+#include <cstring>
 #include <array>
 #include <map>
 #include <string>
@@ -66,6 +67,8 @@ struct Context {
   double* dpart = nullptr;     // partial sums of dot()
   double* zeros = nullptr;     // 16 zeros
   bool big_attr_set = false;
+  void* stage[2] = {nullptr, nullptr};     // pinned staging buffers of the large host <-> device copies
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
 };
 static thread_local Context* t_ctx = nullptr;
 static inline Context& ctx() {
@@ -99,6 +102,7 @@ void destroy_context(Context* c) {
   for (int k = 0; k <= NSIDE; k++) if (c->arena[k]) (void)hipFree(c->arena[k]);
   if (c->dpart) (void)hipFree(c->dpart);
   if (c->zeros) (void)hipFree(c->zeros);
+  for (int k = 0; k < 2; k++) { if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]); }
   for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
   for (auto& e : c->pool) (void)hipEventDestroy(e);
   if (c->ev_init) for (auto& e : c->ev) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
@@ -135,14 +139,70 @@ void* alloc(size_t bytes) {
   return p;
 }
 void free(void* p) { if (p) (void)hipFree(p); }
+// Large copies between pageable host memory and the device: the runtime stages them through a pinned buffer of its own with
+// ONE host thread (7 - 8 GB/s measured on the 5 GB of pull tables of a 256^3 Initialize).  Here two pinned 32 MiB buffers
+// alternate: all setup threads copy a piece into (out of) one while the other is on the bus.  HYMLS_MI_STAGED_COPY=0: off.
+constexpr size_t STAGE_BYTES = (size_t)32 << 20;
+static bool staged_copy(size_t n) {
+  static const bool on = !(std::getenv("HYMLS_MI_STAGED_COPY") && std::atoi(std::getenv("HYMLS_MI_STAGED_COPY")) == 0);
+  if (!on || n < 4 * STAGE_BYTES) return false;
+  Context& c = ctx();
+  for (int k = 0; k < 2; k++) {
+    if (!c.stage[k]) HIP_CHECK(hipHostMalloc(&c.stage[k], STAGE_BYTES, hipHostMallocDefault));
+    if (!c.stage_ev[k]) HIP_CHECK(hipEventCreateWithFlags(&c.stage_ev[k], hipEventDisableTiming));
+  }
+  return true;
+}
+static void host_copy(void* dst, const void* src, size_t n) {
+  constexpr size_t PIECE_BYTES = (size_t)2 << 20;
+  const int64_t np = (int64_t)((n + PIECE_BYTES - 1) / PIECE_BYTES);
+  parallel_for(np, [&](int64_t q) {
+    const size_t o = (size_t)q * PIECE_BYTES;
+    std::memcpy((char*)dst + o, (const char*)src + o, std::min(PIECE_BYTES, n - o));
+  }, 1);
+}
 void h2d(void* d, const void* s, size_t n) {
   if (!n) return;
-  HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream));
+  if (!staged_copy(n)) {
+    HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream));
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    return;
+  }
+  Context& c = ctx();
+  bool used[2] = {false, false};
+  int k = 0;
+  for (size_t off = 0; off < n; off += STAGE_BYTES, k ^= 1) {
+    const size_t len = std::min(STAGE_BYTES, n - off);
+    if (used[k]) HIP_CHECK(hipEventSynchronize(c.stage_ev[k]));      // the transfer that last read this buffer has finished
+    host_copy(c.stage[k], (const char*)s + off, len);
+    HIP_CHECK(hipMemcpyAsync((char*)d + off, c.stage[k], len, hipMemcpyHostToDevice, g_stream));
+    HIP_CHECK(hipEventRecord(c.stage_ev[k], g_stream));
+    used[k] = true;
+  }
   HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 void d2h(void* d, const void* s, size_t n) {
   if (!n) return;
-  HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream));
+  if (!staged_copy(n)) {
+    HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream));
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    return;
+  }
+  Context& c = ctx();
+  // piece q travels into buffer q & 1 while piece q - 1 is copied out of the other one
+  const size_t np = (n + STAGE_BYTES - 1) / STAGE_BYTES;
+  auto issue = [&](size_t q) {
+    const size_t off = q * STAGE_BYTES, len = std::min(STAGE_BYTES, n - off);
+    HIP_CHECK(hipMemcpyAsync(c.stage[q & 1], (const char*)s + off, len, hipMemcpyDeviceToHost, g_stream));
+    HIP_CHECK(hipEventRecord(c.stage_ev[q & 1], g_stream));
+  };
+  issue(0);
+  for (size_t q = 0; q < np; q++) {
+    if (q + 1 < np) issue(q + 1);
+    HIP_CHECK(hipEventSynchronize(c.stage_ev[q & 1]));
+    const size_t off = q * STAGE_BYTES, len = std::min(STAGE_BYTES, n - off);
+    host_copy((char*)d + off, c.stage[q & 1], len);
+  }
   HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 void d2d(void* d, const void* s, size_t n) {
@@ -380,6 +440,26 @@ __global__ void k_pull_sum(int64_t n, const int64_t* __restrict__ ptr, const int
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_pull_sum, dim3(nblocks(n, 256, 65536)), dim3(256), 0, g_stream, n, ptr, idx, in, out); launch_check();
+}
+__global__ void k_build_pull_tables(int64_t nrows, const int64_t* __restrict__ rcount, const int32_t* __restrict__ rowptr,
+                                    const uint64_t* __restrict__ keys, int64_t* __restrict__ ptr, int64_t* __restrict__ idx) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    int64_t e = (int64_t)rowptr[r] - 1;
+    const int64_t k0 = rcount[r], k1 = rcount[r + 1];
+    uint64_t prev = 0;
+    for (int64_t k = k0; k < k1; k++) {
+      const uint64_t key = keys[k], cg = key >> 33;
+      if (k == k0 || cg != prev) { e++; prev = cg; }
+      idx[k] = (int64_t)(key & (((uint64_t)1 << 33) - 1));
+      ptr[e + 1] = k + 1;
+    }
+    if (r == 0) ptr[0] = 0;
+  }
+}
+void build_pull_tables(int64_t nrows, const int64_t* rcount, const int32_t* rowptr, const uint64_t* keys, int64_t* ptr, int64_t* idx) {
+  if (nrows <= 0) { zero(ptr, sizeof(int64_t)); return; }
+  hipLaunchKernelGGL(k_build_pull_tables, dim3(nblocks(nrows, 64, 65536)), dim3(64), 0, g_stream, nrows, rcount, rowptr, keys, ptr, idx);
+  launch_check();
 }
 __global__ void k_pull_sum_blocks(int64_t blen, const int64_t* __restrict__ ptr, const int64_t* __restrict__ base,
                                   const double* __restrict__ in, double* __restrict__ out) {

@@ -168,11 +168,16 @@ HierMap build_hiermap(const Params& p, const std::vector<char>* present, const s
       const int32_t first = S.groups[gi].nodes[0];
       if (!seen[first]) { seen[first] = 1; S.owned.push_back(gi); }
     }
+  }
+  // (the linking needs nothing of the other subdomains: in parallel)
+  parallel_for(nsd, [&](int64_t s) {
+    if (cand && !(*cand)[s]) return;
+    Subdomain& S = h.sd[s];
     ivec all(S.groups.size());
     std::iota(all.begin(), all.end(), 0);
     link_groups(S.groups, all, S.linked);
     link_groups(S.groups, S.owned, S.owned_linked);
-  }
+  }, 16);
   return h;
 }
 

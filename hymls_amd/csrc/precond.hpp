@@ -34,7 +34,7 @@ struct BatchedLU {
   ClassPlan plan;
   ivec members;                 // caller-defined ids (level subdomain ids)
   ivec h_xoff;
-  ivec h_src;                   // [nb][nent]
+  rawvec<int32_t> h_src;        // [nb][nent]
   // device
   dev::PlanD dplan{};
   dev::BatchD batch{};
@@ -120,8 +120,9 @@ class DirectSolver : public Operator {
   void solve(const double* b, double* x, bool zero_fixed);
   void solve_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv, bool zero_fixed);
   Csr prepare(const Csr& A0, const ivec& gids, const ivec& fix_gids, const Params& cp, bool border_pending, ivec& fix_rows);
-  void numeric(const dvec& val);
-  ivec pat_rowptr_, pat_col_, pat_gids_, pat_fix_;   // what the plan was built for
+  void numeric(const vvec& val);
+  ivec pat_rowptr_, pat_gids_, pat_fix_;
+  cvec pat_col_;   // what the plan was built for
   std::vector<char> pat_zero_diag_;
   bool border_pending_ = false;
   int32_t n_ = 0;
@@ -162,8 +163,8 @@ class LevelSolver : public Operator {
   void set_rows(Csr K, ivec gids, dvec tv, int32_t nrows);
   void initialize();
   void compute();                       // uses the host values of K (uploads them)
-  void set_values(const dvec& val);     // SetMatrix with unchanged pattern
-  void swap_values(dvec& val);          // the same without a copy (one rank): takes the array, hands back the old one
+  void set_values(const vvec& val);     // SetMatrix with unchanged pattern
+  void swap_values(vvec& val);          // the same without a copy (one rank): takes the array, hands back the old one
   // b, x: this rank's owned rows (interiors of its subdomains + separators it owns) in the order of owned_gids()
   void apply_inverse(const double* b, double* x) override;
   void apply_inverse_mv(const double* b, int64_t ldb, double* x, int64_t ldx, int nv) override;
@@ -296,7 +297,7 @@ class LevelSolver : public Operator {
   int32_t n_blk_ = 0, n_blk_apply_ = 0, blk_max_nb_ = 0, blk_max_nb_inv_ = 0;   // (_inv_: largest order in the inversion table)
   // rows of the reduced (V-sum) matrix or of the full Schur complement owned here: pattern + pull lists
   Csr red_;                  // col = gid of the column node
-  std::vector<int64_t> red_pull_ptr_, red_pull_idx_;
+  int64_t n_pulls_ = 0;   // summands of the reduced matrix (length of the device-side pull index table)
   int64_t *d_red_pull_ptr_ = nullptr, *d_red_pull_idx_ = nullptr;
   double* d_red_val_ = nullptr;
   double* d_ext_ = nullptr; int64_t ext_total_ = 0;
@@ -308,14 +309,15 @@ class LevelSolver : public Operator {
   ivec glob_clu_ptr_, glob_clu_, glob_sd_center_;   // clusters (subdomains) of the rows of glob_, centres of all subdomains
   ivec glob_gids_;
   dvec glob_tv_;
-  std::vector<int64_t> glob_perm_;      // gathered entry -> entry of glob_
+  rawvec<int64_t> glob_perm_;           // gathered entry -> entry of glob_
   std::vector<int64_t> glob_row_off_;   // first global row of every rank
   bool glob_ready_ = false;
   Csr next_R_;                          // reduced matrix after DropByValue (kept: a recompute reuses its arrays)
   std::unique_ptr<Operator> next_;
   LevelSolver* next_level_ = nullptr;
   bool next_is_direct_ = false;
-  ivec next_pattern_key_rowptr_, next_pattern_key_col_;
+  ivec next_pattern_key_rowptr_;
+  cvec next_pattern_key_col_;
   bool initialized_ = false;
 };
 

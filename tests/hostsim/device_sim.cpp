@@ -79,6 +79,17 @@ void spmv(int32_t nrows, const int32_t* rp, const int32_t* col, const double* va
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out) {
   for (int64_t e = 0; e < n; e++) { double s = 0; for (int64_t t = ptr[e]; t < ptr[e + 1]; t++) s += in[idx[t]]; out[e] = s; }
 }
+void build_pull_tables(int64_t nrows, const int64_t* rcount, const int32_t* rowptr, const uint64_t* keys, int64_t* ptr, int64_t* idx) {
+  ptr[0] = 0;
+  for (int64_t r = 0; r < nrows; r++) {
+    int64_t e = (int64_t)rowptr[r] - 1;
+    for (int64_t k = rcount[r]; k < rcount[r + 1]; k++) {
+      if (k == rcount[r] || (keys[k] >> 33) != (keys[k - 1] >> 33)) e++;
+      idx[k] = (int64_t)(keys[k] & (((uint64_t)1 << 33) - 1));
+      ptr[e + 1] = k + 1;
+    }
+  }
+}
 void pull_sum_blocks(int64_t blen, int32_t nblk, const int64_t* ptr, const int64_t* base, const double* in, double* out) {
   for (int B = 0; B < nblk; B++)
     for (int64_t k = 0; k < blen; k++) { double s = 0; for (int64_t t = ptr[B]; t < ptr[B + 1]; t++) s += in[base[t] + k]; out[(int64_t)B * blen + k] = s; }

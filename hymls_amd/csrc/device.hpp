@@ -139,6 +139,11 @@ void spmv(int32_t nrows, const int32_t* rowptr, const int32_t* col, const double
           const double* x, double* y, double alpha, double beta, int64_t nnz_hint = -1);
 // out[e] = sum_{t in [ptr[e],ptr[e+1])} in[idx[t]]   (deterministic pull-assembly)
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out);
+// entry source lists of the members of a pattern class, built on the device: src[b][q] = index in the level matrix (CSR krow /
+// kcol, rows with ascending columns) of entry q of member b's extended local CSR, whose row and column are positions ent_row[q]
+// and ent_col[q] in the member's node list ext[b][0 .. next).  *flag |= 1 when an entry is not found.
+void member_sources(int32_t nb, int32_t next, int32_t nent, const int32_t* ext, const int32_t* ent_row, const int32_t* ent_col,
+                    const int32_t* krow, const int32_t* kcol, int32_t* src, int32_t* flag);
 // pull tables of the reduced matrix from its sorted keys (column gid << 33 | source position), rows [rcount[r], rcount[r+1])
 // of the key array, entries [rowptr[r], rowptr[r+1]) of the matrix: idx[k] = source of key k, ptr[e] .. ptr[e+1] = the keys
 // of entry e (a run of equal column gids)

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <dlfcn.h>
+#include <chrono>
 #include <cstring>
 #include <array>
 #include <map>
@@ -67,8 +68,6 @@ struct Context {
   double* dpart = nullptr;     // partial sums of dot()
   double* zeros = nullptr;     // 16 zeros
   bool big_attr_set = false;
-  void* stage[2] = {nullptr, nullptr};     // pinned staging buffers of the large host <-> device copies
-  hipEvent_t stage_ev[2] = {nullptr, nullptr};
 };
 static thread_local Context* t_ctx = nullptr;
 static inline Context& ctx() {
@@ -102,7 +101,6 @@ void destroy_context(Context* c) {
   for (int k = 0; k <= NSIDE; k++) if (c->arena[k]) (void)hipFree(c->arena[k]);
   if (c->dpart) (void)hipFree(c->dpart);
   if (c->zeros) (void)hipFree(c->zeros);
-  for (int k = 0; k < 2; k++) { if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]); }
   for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
   for (auto& e : c->pool) (void)hipEventDestroy(e);
   if (c->ev_init) for (auto& e : c->ev) { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); }
@@ -135,74 +133,25 @@ void join_streams() {
 }
 void* alloc(size_t bytes) {
   void* p = nullptr;
+  static const bool fine = std::getenv("HYMLS_MI_VERBOSE") && std::atoi(std::getenv("HYMLS_MI_VERBOSE")) >= 2;
+  const auto t0 = std::chrono::steady_clock::now();
   HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 8)));
+  if (fine && bytes >= ((size_t)1 << 30))
+    std::fprintf(stderr, "[hymls_mi]       . hipMalloc of %.1f GiB %.3f s\n", bytes / 1073741824.0,
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   return p;
 }
 void free(void* p) { if (p) (void)hipFree(p); }
-// Large copies between pageable host memory and the device: the runtime stages them through a pinned buffer of its own with
-// ONE host thread (7 - 8 GB/s measured on the 5 GB of pull tables of a 256^3 Initialize).  Here two pinned 32 MiB buffers
-// alternate: all setup threads copy a piece into (out of) one while the other is on the bus.  HYMLS_MI_STAGED_COPY=0: off.
-constexpr size_t STAGE_BYTES = (size_t)32 << 20;
-static bool staged_copy(size_t n) {
-  static const bool on = !(std::getenv("HYMLS_MI_STAGED_COPY") && std::atoi(std::getenv("HYMLS_MI_STAGED_COPY")) == 0);
-  if (!on || n < 4 * STAGE_BYTES) return false;
-  Context& c = ctx();
-  for (int k = 0; k < 2; k++) {
-    if (!c.stage[k]) HIP_CHECK(hipHostMalloc(&c.stage[k], STAGE_BYTES, hipHostMallocDefault));
-    if (!c.stage_ev[k]) HIP_CHECK(hipEventCreateWithFlags(&c.stage_ev[k], hipEventDisableTiming));
-  }
-  return true;
-}
-static void host_copy(void* dst, const void* src, size_t n) {
-  constexpr size_t PIECE_BYTES = (size_t)2 << 20;
-  const int64_t np = (int64_t)((n + PIECE_BYTES - 1) / PIECE_BYTES);
-  parallel_for(np, [&](int64_t q) {
-    const size_t o = (size_t)q * PIECE_BYTES;
-    std::memcpy((char*)dst + o, (const char*)src + o, std::min(PIECE_BYTES, n - o));
-  }, 1);
-}
+// (Measured, tools/copy_rate.py: a plain hipMemcpy from / to pageable memory runs at 54 - 56 GB/s on this platform, the same as
+// a copy staged through two pinned buffers by all setup threads: no staging here.)
 void h2d(void* d, const void* s, size_t n) {
   if (!n) return;
-  if (!staged_copy(n)) {
-    HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream));
-    HIP_CHECK(hipStreamSynchronize(g_stream));
-    return;
-  }
-  Context& c = ctx();
-  bool used[2] = {false, false};
-  int k = 0;
-  for (size_t off = 0; off < n; off += STAGE_BYTES, k ^= 1) {
-    const size_t len = std::min(STAGE_BYTES, n - off);
-    if (used[k]) HIP_CHECK(hipEventSynchronize(c.stage_ev[k]));      // the transfer that last read this buffer has finished
-    host_copy(c.stage[k], (const char*)s + off, len);
-    HIP_CHECK(hipMemcpyAsync((char*)d + off, c.stage[k], len, hipMemcpyHostToDevice, g_stream));
-    HIP_CHECK(hipEventRecord(c.stage_ev[k], g_stream));
-    used[k] = true;
-  }
+  HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream));
   HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 void d2h(void* d, const void* s, size_t n) {
   if (!n) return;
-  if (!staged_copy(n)) {
-    HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream));
-    HIP_CHECK(hipStreamSynchronize(g_stream));
-    return;
-  }
-  Context& c = ctx();
-  // piece q travels into buffer q & 1 while piece q - 1 is copied out of the other one
-  const size_t np = (n + STAGE_BYTES - 1) / STAGE_BYTES;
-  auto issue = [&](size_t q) {
-    const size_t off = q * STAGE_BYTES, len = std::min(STAGE_BYTES, n - off);
-    HIP_CHECK(hipMemcpyAsync(c.stage[q & 1], (const char*)s + off, len, hipMemcpyDeviceToHost, g_stream));
-    HIP_CHECK(hipEventRecord(c.stage_ev[q & 1], g_stream));
-  };
-  issue(0);
-  for (size_t q = 0; q < np; q++) {
-    if (q + 1 < np) issue(q + 1);
-    HIP_CHECK(hipEventSynchronize(c.stage_ev[q & 1]));
-    const size_t off = q * STAGE_BYTES, len = std::min(STAGE_BYTES, n - off);
-    host_copy((char*)d + off, c.stage[q & 1], len);
-  }
+  HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream));
   HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 void d2d(void* d, const void* s, size_t n) {
@@ -440,6 +389,31 @@ __global__ void k_pull_sum(int64_t n, const int64_t* __restrict__ ptr, const int
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_pull_sum, dim3(nblocks(n, 256, 65536)), dim3(256), 0, g_stream, n, ptr, idx, in, out); launch_check();
+}
+__global__ void __launch_bounds__(256) k_member_sources(int32_t next, int32_t nent, const int32_t* __restrict__ ext,
+                                                        const int32_t* __restrict__ ent_row, const int32_t* __restrict__ ent_col,
+                                                        const int32_t* __restrict__ krow, const int32_t* __restrict__ kcol,
+                                                        int32_t* __restrict__ src, int32_t* __restrict__ flag) {
+  const int b = blockIdx.y;
+  const int32_t* nodes = ext + (int64_t)b * next;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nent; q += gridDim.x * blockDim.x) {
+    const int32_t r = nodes[ent_row[q]], c = nodes[ent_col[q]];
+    int32_t lo = krow[r], hi = krow[r + 1];          // first entry of the row with column >= c
+    while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (kcol[mid] < c) lo = mid + 1; else hi = mid; }
+    const bool found = lo < krow[r + 1] && kcol[lo] == c;
+    if (!found) atomicOr(flag, 1);
+    src[(int64_t)b * nent + q] = found ? lo : 0;
+  }
+}
+void member_sources(int32_t nb, int32_t next, int32_t nent, const int32_t* ext, const int32_t* ent_row, const int32_t* ent_col,
+                    const int32_t* krow, const int32_t* kcol, int32_t* src, int32_t* flag) {
+  if (nb <= 0 || nent <= 0) return;
+  for (int b0 = 0; b0 < nb; b0 += 65535) {
+    const int n = std::min(65535, nb - b0);
+    hipLaunchKernelGGL(k_member_sources, dim3(nblocks(nent, 256, 64), n), dim3(256), 0, g_stream, next, nent, ext + (int64_t)b0 * next, ent_row,
+                       ent_col, krow, kcol, src + (int64_t)b0 * nent, flag);
+    launch_check();
+  }
 }
 __global__ void k_build_pull_tables(int64_t nrows, const int64_t* __restrict__ rcount, const int32_t* __restrict__ rowptr,
                                     const uint64_t* __restrict__ keys, int64_t* __restrict__ ptr, int64_t* __restrict__ idx) {

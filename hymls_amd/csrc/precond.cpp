@@ -155,7 +155,25 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   const int64_t per = plan.scratch_size + (with_sblock ? (int64_t)plan.nS * plan.nS : 0);
   chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nb, budget / std::max<int64_t>(per, 1)));
   batch.nb = nb;
-  batch.src = keep(dev::upload(h_src));
+  if (!h_ext.empty()) {
+    HYMLS_CHECK(d_krow && d_kcol && (int64_t)h_ent_row.size() == nent && (int64_t)h_ext.size() == (int64_t)nb * n_ext, -3,
+                "entry source lists: inconsistent tables");
+    int32_t* src = (int32_t*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)nb * nent) * sizeof(int32_t)));
+    int32_t* d_ext = dev::upload(h_ext);
+    int32_t* d_er = dev::upload(h_ent_row);
+    int32_t* d_ec = dev::upload(h_ent_col);
+    int32_t* d_fl = (int32_t*)dev::alloc(sizeof(int32_t));
+    dev::zero(d_fl, sizeof(int32_t));
+    dev::member_sources(nb, n_ext, nent, d_ext, d_er, d_ec, d_krow, d_kcol, src, d_fl);
+    int32_t fl = 0;
+    dev::d2h(&fl, d_fl, sizeof fl);
+    dev::free(d_ext); dev::free(d_er); dev::free(d_ec); dev::free(d_fl);
+    HYMLS_CHECK(fl == 0, -3, "entry of a subdomain pattern not found in the level matrix");
+    batch.src = src;
+    { rawvec<int32_t>().swap(h_ext); }
+  } else {
+    batch.src = keep(dev::upload(h_src));
+  }
   batch.xoff = keep(dev::upload(h_xoff));
   batch.factor = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)nb * plan.factor_size) * sizeof(double)));
   // frontal scratch / separator blocks / pivot workspace are borrowed from the shared arena at factor time
@@ -973,10 +991,12 @@ void LevelSolver::initialize() {
   }
   fine("A21 count / prefix / fill + halo plans");
   lap("A12/A21 + halo plans");
+  // the pattern of the level matrix goes to the device first: the classes build their entry source lists from it there
+  d_krow_ = dev::upload(K_.rowptr); d_kcol_ = dev::upload(K_.col);
+  for (auto& cp : cls_) { cp->lu.d_krow = d_krow_; cp->lu.d_kcol = d_kcol_; }
   build_schur_setup();
   lap("Schur setup + uploads");
   // device residents
-  d_krow_ = dev::upload(K_.rowptr); d_kcol_ = dev::upload(K_.col);
   d_kval_ = (double*)dev::alloc(std::max<size_t>(1, K_.val.size()) * sizeof(double));
   d_inperm_ = dev::upload(in_perm_);
   d_z_ = (double*)dev::alloc((size_t)std::max(n1_ + ngi_ + n2_, 1) * sizeof(double));
@@ -1035,7 +1055,14 @@ void LevelSolver::build_classes() {
   fine("(classes) subdomain centres");
   (void)n;
   // ---- pass 1: extended local pattern of every subdomain (in parallel, chunk by chunk), then classification
-  struct SdPat { LocalPattern lp; ivec src, mult, lgptr, key_extra; uint64_t hash = 0; std::string err; };
+  struct SdPat { LocalPattern lp; ivec src, ext, mult, lgptr, key_extra; uint64_t hash = 0; std::string err; };
+  // rows of the level matrix with strictly ascending columns: the device finds the entries of every member itself
+  // (dev::member_sources) from the members' node lists; otherwise the lists are built here, entry by entry
+  std::atomic<int> unsorted{0};
+  parallel_for(K_.n, [&](int64_t r) {
+    for (int e = K_.rowptr[r] + 1; e < K_.rowptr[r + 1]; e++) if (K_.col[e] <= K_.col[e - 1]) { unsorted = 1; break; }
+  }, 1 << 14);
+  const bool device_src = unsorted == 0 && !std::getenv("HYMLS_MI_HOST_SOURCE_LISTS");
   static std::atomic<long long> tprof[6];
   auto tnow = []() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto build_pattern = [&](int s, SdPat& out) {
@@ -1087,7 +1114,8 @@ void LevelSolver::build_classes() {
           m = common(pos2_[r], pos2_[c]);
           if (m <= 0) { out.err = "separator coupling not inside any subdomain"; return; }
         }
-        lp.col.push_back(lc); out.src.push_back(e); out.mult.push_back(m);
+        lp.col.push_back(lc); out.mult.push_back(m);
+        if (!device_src) out.src.push_back(e);
         lp.weight.push_back(1.0 / m);
         if (lc == i && i < lp.nI && K_.val[e] != 0.0) lp.zero_diag[i] = 0;
       }
@@ -1118,6 +1146,7 @@ void LevelSolver::build_classes() {
     H.addv(lp.rowptr); H.addv(lp.col); H.addv(lp.zero_diag); H.addv(lp.coord); H.addv(out.mult);
     H.addv(out.lgptr); H.addv(out.key_extra);
     out.hash = H.h;
+    if (device_src) out.ext.swap(ext_rows);
     lapq(2);
   };
   std::unordered_map<uint64_t, std::vector<int>> table;
@@ -1177,7 +1206,7 @@ void LevelSolver::build_classes() {
         sd_cls_[s] = cid;
         // the class's entry numbering (plan.ent_id refers to the extended CSR) mapped onto this member: kept per
         // subdomain and copied into the class arrays below, in parallel and without reallocation
-        sd_src[s].swap(Pt.src);
+        sd_src[s].swap(device_src ? Pt.ext : Pt.src);
       }
     }, 1);
     HYMLS_CHECK(err_k < 0, err_msg.find("decouple") != std::string::npos ? -2 : -3, err_msg);
@@ -1202,13 +1231,20 @@ void LevelSolver::build_classes() {
   lap_bc("patterns + class lookup");
   for (size_t c = first_new; c < cls_.size(); c++) {
     Cls& C = *cls_[c];
-    const size_t ne = C.pat.col.size();
-    C.lu.h_src.resize(ne * C.lu.members.size());
+    const size_t ne = device_src ? (size_t)(C.pat.nI + C.pat.nS) : C.pat.col.size();
+    rawvec<int32_t>& dst = device_src ? C.lu.h_ext : C.lu.h_src;
+    dst.resize(ne * C.lu.members.size());
     parallel_for((int64_t)C.lu.members.size(), [&](int64_t b) {
       ivec& v = sd_src[C.lu.members[b]];
-      std::copy(v.begin(), v.end(), C.lu.h_src.begin() + (size_t)b * ne);
+      std::copy(v.begin(), v.end(), dst.begin() + (size_t)b * ne);
       ivec().swap(v);
     }, 64);
+    if (device_src) {
+      C.lu.n_ext = (int32_t)ne;
+      C.lu.h_ent_col.assign(C.pat.col.begin(), C.pat.col.end());
+      C.lu.h_ent_row.resize(C.pat.col.size());
+      for (int i = 0; i < C.pat.nI + C.pat.nS; i++) for (int q = C.pat.rowptr[i]; q < C.pat.rowptr[i + 1]; q++) C.lu.h_ent_row[q] = i;
+    }
   }
   lap_bc("entry source lists");
   // ---- pass 2: symbolic analysis of every class (independent: in parallel)

@@ -34,7 +34,14 @@ struct BatchedLU {
   ClassPlan plan;
   ivec members;                 // caller-defined ids (level subdomain ids)
   ivec h_xoff;
-  rawvec<int32_t> h_src;        // [nb][nent]
+  rawvec<int32_t> h_src;        // [nb][nent] entry of the level matrix behind every entry of the extended local CSR ...
+  // ... or, when the rows of the level matrix have ascending columns, what the device needs to find them itself
+  // (dev::member_sources): the nodes of every member in the order of the extended local numbering, and row / column of
+  // every entry of the class's extended CSR
+  rawvec<int32_t> h_ext;        // [nb][n_ext]
+  int32_t n_ext = 0;
+  ivec h_ent_row, h_ent_col;    // [nent]
+  const int32_t *d_krow = nullptr, *d_kcol = nullptr;   // the level matrix on the device (not owned)
   // device
   dev::PlanD dplan{};
   dev::BatchD batch{};

@@ -7,6 +7,7 @@
 // contains the HIP implementation (device_hip.hip) and no CPU path.
 #include "device.hpp"
 #include "comm.hpp"
+#include <algorithm>
 #include <cstring>
 #include <chrono>
 
@@ -78,6 +79,19 @@ void spmv(int32_t nrows, const int32_t* rp, const int32_t* col, const double* va
 }
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out) {
   for (int64_t e = 0; e < n; e++) { double s = 0; for (int64_t t = ptr[e]; t < ptr[e + 1]; t++) s += in[idx[t]]; out[e] = s; }
+}
+void member_sources(int32_t nb, int32_t next, int32_t nent, const int32_t* ext, const int32_t* ent_row, const int32_t* ent_col,
+                    const int32_t* krow, const int32_t* kcol, int32_t* src, int32_t* flag) {
+  for (int b = 0; b < nb; b++) {
+    const int32_t* nodes = ext + (int64_t)b * next;
+    for (int q = 0; q < nent; q++) {
+      const int32_t r = nodes[ent_row[q]], c = nodes[ent_col[q]];
+      const int32_t* f = std::lower_bound(kcol + krow[r], kcol + krow[r + 1], c);
+      const bool found = f < kcol + krow[r + 1] && *f == c;
+      if (!found) *flag |= 1;
+      src[(int64_t)b * nent + q] = found ? (int32_t)(f - kcol) : 0;
+    }
+  }
 }
 void build_pull_tables(int64_t nrows, const int64_t* rcount, const int32_t* rowptr, const uint64_t* keys, int64_t* ptr, int64_t* idx) {
   ptr[0] = 0;

@@ -119,14 +119,16 @@ int hymls_mi_set_matrix_csr(hymls_mi_t* h, int64_t n, const int32_t* rowptr, con
   HYMLS_CHECK(n == N, -2, "matrix size does not match nx*ny*nz*dof");
   const int64_t nnz = rowptr[n];
   const bool same = h->have_matrix && h->K.n == n && (int64_t)h->K.col.size() == nnz &&
-                    std::memcmp(h->K.rowptr.data(), rowptr, (n + 1) * 4) == 0 &&
-                    std::memcmp(h->K.col.data(), colind, nnz * 4) == 0;
+                    parallel_equal(h->K.rowptr.data(), rowptr, (size_t)(n + 1) * 4) &&
+                    parallel_equal(h->K.col.data(), colind, (size_t)nnz * 4);
   h->K.n = (int32_t)n;
-  h->K.rowptr.assign(rowptr, rowptr + n + 1);
-  h->K.col.assign(colind, colind + nnz);
-  h->K.val.assign(val, val + nnz);
-  h->gids.resize(n);
-  std::iota(h->gids.begin(), h->gids.end(), 0);
+  if (!same) {
+    parallel_assign(h->K.rowptr, rowptr, (size_t)n + 1);
+    parallel_assign(h->K.col, colind, (size_t)nnz);
+    h->gids.resize(n);
+    parallel_for(n, [&](int64_t i) { h->gids[i] = (int32_t)i; }, 1 << 16);
+  }
+  parallel_assign(h->K.val, val, (size_t)nnz);
   h->nrows = (int32_t)n;
   h->have_matrix = true;
   h->computed = false;
@@ -274,12 +276,12 @@ int hymls_mi_set_matrix_rows(hymls_mi_t* h, int64_t nrows, const int32_t* gids, 
   API_BEGIN
   const int64_t nnz = rowptr[nrows];
   const bool same = h->have_matrix && h->nrows == nrows && (int64_t)h->rows_colgid.size() == nnz &&
-                    std::memcmp(h->gids.data(), gids, nrows * 4) == 0 &&
-                    std::memcmp(h->rows_rowptr.data(), rowptr, (nrows + 1) * 4) == 0 &&
-                    std::memcmp(h->rows_colgid.data(), colgid, nnz * 4) == 0;
+                    parallel_equal(h->gids.data(), gids, (size_t)nrows * 4) &&
+                    parallel_equal(h->rows_rowptr.data(), rowptr, (size_t)(nrows + 1) * 4) &&
+                    parallel_equal(h->rows_colgid.data(), colgid, (size_t)nnz * 4);
   h->computed = false;
   if (same && h->top && h->initialized) {
-    h->K.val.assign(val, val + nnz);
+    parallel_assign(h->K.val, val, (size_t)nnz);
     h->top->set_values(h->K.val);
   } else {
     make_local_csr(nrows, gids, rowptr, colgid, val, h->ngid(), h->K, h->gids);

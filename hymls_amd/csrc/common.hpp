@@ -11,6 +11,8 @@
 #include <cmath>
 #include <thread>
 #include <memory>
+#include <cstring>
+#include <atomic>
 #include <mutex>
 #include <exception>
 
@@ -110,6 +112,31 @@ void parallel_for(int64_t n, Fn fn, int64_t grain = 256) {
   if (err) std::rethrow_exception(err);
 }
 
+// memcpy / memcmp of gigabytes on the setup threads (the matrix of a 256^3 run is 12 GB: a serial copy takes two seconds)
+inline void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+  constexpr size_t CH = (size_t)8 << 20;
+  if (bytes < 4 * CH) { if (bytes) std::memcpy(dst, src, bytes); return; }
+  parallel_for((int64_t)((bytes + CH - 1) / CH), [&](int64_t q) {
+    const size_t o = (size_t)q * CH;
+    std::memcpy((char*)dst + o, (const char*)src + o, std::min(CH, bytes - o));
+  }, 1);
+}
+inline bool parallel_equal(const void* a, const void* b, size_t bytes) {
+  constexpr size_t CH = (size_t)8 << 20;
+  if (bytes < 4 * CH) return bytes == 0 || std::memcmp(a, b, bytes) == 0;
+  std::atomic<int> diff{0};
+  parallel_for((int64_t)((bytes + CH - 1) / CH), [&](int64_t q) {
+    const size_t o = (size_t)q * CH;
+    if (!diff && std::memcmp((const char*)a + o, (const char*)b + o, std::min(CH, bytes - o)) != 0) diff = 1;
+  }, 1);
+  return diff == 0;
+}
+// vector <- array, copied on the setup threads (resize() of a rawvec does not touch the memory first)
+template <class V, class T>
+void parallel_assign(V& v, const T* src, size_t n) {
+  v.resize(n);
+  parallel_memcpy(v.data(), src, n * sizeof(T));
+}
 // in-place inclusive prefix sum of a[0 .. n) on the setup threads (chunk sums, their serial scan, offsets added in parallel)
 template <class T>
 void parallel_inclusive_scan(T* a, int64_t n) {

@@ -17,6 +17,7 @@ namespace dev {
 struct Context;
 Context* create_context(int device);   // throws -3 without a HIP device, -2 for a bad ordinal
 void bind(Context* c);                 // make c current on this thread (selects its device); nullptr: unbind
+Context* current();                    // the context bound to this thread (nullptr: none)
 void destroy_context(Context* c);
 void* stream();                        // hipStream_t of the bound context (nullptr in the simulator)
 const double* zeros16();               // 16 device zeros (bound context)
@@ -139,6 +140,14 @@ void spmv(int32_t nrows, const int32_t* rowptr, const int32_t* col, const double
           const double* x, double* y, double alpha, double beta, int64_t nnz_hint = -1);
 // out[e] = sum_{t in [ptr[e],ptr[e+1])} in[idx[t]]   (deterministic pull-assembly)
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out);
+// Off-diagonal blocks of the level matrix (A12, A21) cut out on the device: for the matrix rows rows[0 .. nrows) keep the
+// entries whose column c has a target, target(c) = ta[c] if ta[c] >= 0, else tb[c] if tb is given and excl[c] < 0, else none.
+// offdiag_count writes the kept entries of row t to count[t + 1] (count[0] untouched); offdiag_fill writes their targets and
+// their positions in the level matrix behind rowptr[t].
+void offdiag_count(int64_t nrows, const int32_t* rows, const int32_t* krow, const int32_t* kcol, const int32_t* ta, const int32_t* tb,
+                   const int32_t* excl, int32_t* count);
+void offdiag_fill(int64_t nrows, const int32_t* rows, const int32_t* krow, const int32_t* kcol, const int32_t* ta, const int32_t* tb,
+                  const int32_t* excl, const int32_t* rowptr, int32_t* col, int32_t* src);
 // entry source lists of the members of a pattern class, built on the device: src[b][q] = index in the level matrix (CSR krow /
 // kcol, rows with ascending columns) of entry q of member b's extended local CSR, whose row and column are positions ent_row[q]
 // and ent_col[q] in the member's node list ext[b][0 .. next).  *flag |= 1 when an entry is not found.

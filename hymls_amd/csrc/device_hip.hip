@@ -90,6 +90,7 @@ Context* create_context(int device) {
   c->cur = c->main;
   return c;
 }
+Context* current() { return t_ctx; }
 void bind(Context* c) {
   t_ctx = c;
   if (c) HIP_CHECK(hipSetDevice(c->device));
@@ -389,6 +390,39 @@ __global__ void k_pull_sum(int64_t n, const int64_t* __restrict__ ptr, const int
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_pull_sum, dim3(nblocks(n, 256, 65536)), dim3(256), 0, g_stream, n, ptr, idx, in, out); launch_check();
+}
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_offdiag(int64_t nrows, const int32_t* __restrict__ rows, const int32_t* __restrict__ krow,
+                                                 const int32_t* __restrict__ kcol, const int32_t* __restrict__ ta, const int32_t* __restrict__ tb,
+                                                 const int32_t* __restrict__ excl, const int32_t* __restrict__ rowptr, int32_t* __restrict__ out,
+                                                 int32_t* __restrict__ src) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nrows; t += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t r = rows[t];
+    int32_t o = FILL ? rowptr[t] : 0;
+    for (int32_t e = krow[r]; e < krow[r + 1]; e++) {
+      const int32_t c = kcol[e];
+      int32_t tg = ta[c];
+      if (tg < 0 && tb && excl[c] < 0) tg = tb[c];
+      if (tg < 0) continue;
+      if (FILL) { out[o] = tg; src[o] = e; }
+      o++;
+    }
+    if (!FILL) out[t + 1] = o;
+  }
+}
+void offdiag_count(int64_t nrows, const int32_t* rows, const int32_t* krow, const int32_t* kcol, const int32_t* ta, const int32_t* tb,
+                   const int32_t* excl, int32_t* count) {
+  if (nrows <= 0) return;
+  hipLaunchKernelGGL(k_offdiag<false>, dim3(nblocks(nrows, 256, 1 << 20)), dim3(256), 0, g_stream, nrows, rows, krow, kcol, ta, tb, excl,
+                     (const int32_t*)nullptr, count, (int32_t*)nullptr);
+  launch_check();
+}
+void offdiag_fill(int64_t nrows, const int32_t* rows, const int32_t* krow, const int32_t* kcol, const int32_t* ta, const int32_t* tb,
+                  const int32_t* excl, const int32_t* rowptr, int32_t* col, int32_t* src) {
+  if (nrows <= 0) return;
+  hipLaunchKernelGGL(k_offdiag<true>, dim3(nblocks(nrows, 256, 1 << 20)), dim3(256), 0, g_stream, nrows, rows, krow, kcol, ta, tb, excl,
+                     rowptr, col, src);
+  launch_check();
 }
 __global__ void __launch_bounds__(256) k_member_sources(int32_t next, int32_t nent, const int32_t* __restrict__ ext,
                                                         const int32_t* __restrict__ ent_row, const int32_t* __restrict__ ent_col,

@@ -175,7 +175,9 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
     batch.src = keep(dev::upload(h_src));
   }
   batch.xoff = keep(dev::upload(h_xoff));
-  batch.factor = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)nb * plan.factor_size) * sizeof(double)));
+  const size_t fbytes = factor_bytes(nb, plan.factor_size);
+  batch.factor = (double*)keep(pre_factor && pre_factor->bytes == fbytes ? pre_factor->take() : dev::alloc(fbytes));
+  pre_factor.reset();
   // frontal scratch / separator blocks / pivot workspace are borrowed from the shared arena at factor time
   scratch_need_ = std::max<int64_t>(1, (int64_t)chunk * plan.scratch_size);
   sblock_need_ = with_sblock ? std::max<int64_t>(1, (int64_t)chunk * plan.nS * plan.nS) : 0;
@@ -710,8 +712,15 @@ LevelSolver::~LevelSolver() {
   for (auto& b : blocks_) { dev::free(b.d_binv); dev::free(b.d_ids); dev::free(b.d_pull_ptr); dev::free(b.d_pull_base); }
 }
 
-void LevelSolver::set_rows(Csr K, ivec gids, dvec tv, int32_t nrows) {
-  K_ = std::move(K); gids_ = std::move(gids); tv_ = std::move(tv); nrows_ = nrows;
+void LevelSolver::set_rows(const Csr& K, const ivec& gids, const dvec& tv, int32_t nrows) {
+  // (copies on the setup threads: 12 GB at the finest level of a 256^3 run)
+  K_.n = K.n;
+  parallel_assign(K_.rowptr, K.rowptr.data(), K.rowptr.size());
+  parallel_assign(K_.col, K.col.data(), K.col.size());
+  parallel_assign(K_.val, K.val.data(), K.val.size());
+  parallel_assign(gids_, gids.data(), gids.size());
+  parallel_assign(tv_, tv.data(), tv.size());
+  nrows_ = nrows;
   HYMLS_CHECK((int)gids_.size() == K_.n && nrows_ <= K_.n, -2, "level: inconsistent sizes");
   tv_.resize(K_.n, 1.0);
 }
@@ -905,6 +914,11 @@ void LevelSolver::initialize() {
   direct_schur_ = level_ >= p_.levels;
   lap("separator numbering");
   build_classes();
+  // the large factor arrays are requested now, on helper threads: the allocations pass while the tables below are built
+  for (auto& cp : cls_) {
+    const size_t fb = BatchedLU::factor_bytes((int64_t)cp->lu.members.size(), cp->lu.plan.factor_size);
+    if (fb >= ((size_t)1 << 30) && !cp->lu.pre_factor) cp->lu.pre_factor.reset(new AsyncAlloc(fb));
+  }
   lap("pattern classes + plans");
   fine.t = wall();
   // owned rows = layout of the vectors handed to apply_inverse (order of the rows as they were given)
@@ -931,25 +945,7 @@ void LevelSolver::initialize() {
   parallel_for(n, [&](int64_t i) { if (intidx_[i] >= 0) row_of_internal[intidx_[i]] = (int32_t)i; }, 1 << 16);
   a12_row_.assign(n1_ + 1, 0); a21_row_.assign(n2_ + 1, 0);
   fine("row_of_internal");
-  // A12: count, prefix, fill (rows in parallel)
-  parallel_for(n1_, [&](int64_t t) {
-    const int r = row_of_internal[t];
-    int32_t c = 0;
-    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) c += pos2_[K_.col[e]] >= 0;
-    a12_row_[t + 1] = c;
-  });
-  parallel_inclusive_scan(a12_row_.data(), (int64_t)n1_ + 1);
-  a12_col_.assign((size_t)a12_row_[n1_], 0); a12_src_.assign((size_t)a12_row_[n1_], 0);
-  parallel_for(n1_, [&](int64_t t) {
-    const int r = row_of_internal[t];
-    int32_t o = a12_row_[t];
-    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
-      const int c = K_.col[e];
-      if (pos2_[c] >= 0) { a12_col_[o] = pos2_[c]; a12_src_[o] = e; o++; }
-    }
-  });
-  fine("A12 count / prefix / fill");
-  // A21: ghost interior columns are numbered first (sequential over the few boundary rows), then count / fill
+  // ghost interior columns of A21 are numbered first (sequential over the few boundary rows)
   std::vector<std::vector<int64_t>> want_int(comm_->size);
   std::vector<ivec> dst_int(comm_->size);
   ivec ghost_idx(dist ? n : 0, -1);
@@ -967,23 +963,39 @@ void LevelSolver::initialize() {
         }
       }
     }
-  auto a21_target = [&](int c) { return intidx_[c] >= 0 ? intidx_[c] : ((dist && pos2_[c] < 0) ? ghost_idx[c] : -1); };
-  parallel_for(n2_, [&](int64_t k) {
-    const int r = sep_row_[k];
-    int32_t c = 0;
-    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) c += a21_target(K_.col[e]) >= 0;
-    a21_row_[k + 1] = c;
-  });
-  parallel_inclusive_scan(a21_row_.data(), (int64_t)n2_ + 1);
-  a21_col_.assign((size_t)a21_row_[n2_], 0); a21_src_.assign((size_t)a21_row_[n2_], 0);
-  parallel_for(n2_, [&](int64_t k) {
-    const int r = sep_row_[k];
-    int32_t o = a21_row_[k];
-    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
-      const int t = a21_target(K_.col[e]);
-      if (t >= 0) { a21_col_[o] = t; a21_src_[o] = e; o++; }
-    }
-  });
+  // The two blocks are cut out of the level matrix on the device (its pattern is there already): count per row, prefix sum
+  // on the host threads, fill.  The tables stay on the device; the host keeps copies (border set-up, sizes).
+  //   A12: interior rows, columns = separators incl. ghosts (target pos2)
+  //   A21: owned separator rows, columns = interiors (target intidx), sharded: + the neighbours' interior layer (ghost_idx)
+  d_krow_ = dev::upload(K_.rowptr); d_kcol_ = dev::upload(K_.col);
+  {
+    int32_t* d_pos2 = dev::upload(pos2_);
+    int32_t* d_int = dev::upload(intidx_);
+    int32_t* d_ghost = dist ? dev::upload(ghost_idx) : nullptr;
+    int32_t* d_rows1 = dev::upload(row_of_internal);
+    ivec sep_rows(sep_row_.begin(), sep_row_.begin() + n2_);
+    int32_t* d_rows2 = dev::upload(sep_rows);
+    auto cut = [&](int64_t nr, const int32_t* d_rows, const int32_t* ta, const int32_t* tb, const int32_t* excl, ivec& row, cvec& col,
+                   cvec& src, int32_t*& d_row, int32_t*& d_col, int32_t*& d_src) {
+      d_row = (int32_t*)dev::alloc((size_t)(nr + 1) * sizeof(int32_t));
+      dev::zero(d_row, sizeof(int32_t));
+      dev::offdiag_count(nr, d_rows, d_krow_, d_kcol_, ta, tb, excl, d_row);
+      dev::d2h(row.data(), d_row, (size_t)(nr + 1) * sizeof(int32_t));
+      parallel_inclusive_scan(row.data(), nr + 1);
+      dev::h2d(d_row, row.data(), (size_t)(nr + 1) * sizeof(int32_t));
+      const size_t nz = (size_t)row[nr];
+      d_col = (int32_t*)dev::alloc(std::max<size_t>(1, nz) * sizeof(int32_t));
+      d_src = (int32_t*)dev::alloc(std::max<size_t>(1, nz) * sizeof(int32_t));
+      dev::offdiag_fill(nr, d_rows, d_krow_, d_kcol_, ta, tb, excl, d_row, d_col, d_src);
+      col.resize(nz); src.resize(nz);
+      if (nz) { dev::d2h(col.data(), d_col, nz * sizeof(int32_t)); dev::d2h(src.data(), d_src, nz * sizeof(int32_t)); }
+    };
+    cut(n1_, d_rows1, d_pos2, nullptr, nullptr, a12_row_, a12_col_, a12_src_, d_a12_row_, d_a12_col_, d_a12_src_);
+    fine("A12 count / prefix / fill (device)");
+    cut(n2_, d_rows2, d_int, d_ghost, d_pos2, a21_row_, a21_col_, a21_src_, d_a21_row_, d_a21_col_, d_a21_src_);
+    dev::sync();
+    dev::free(d_pos2); dev::free(d_int); dev::free(d_ghost); dev::free(d_rows1); dev::free(d_rows2);
+  }
   if (dist) {
     // x1 of the neighbours' interiors next to separators owned here; x2 of the separators owned elsewhere
     xch_int_.build(*comm_, want_int, dst_int, [&](int64_t g) { const int l = g2l_[g]; return l >= 0 ? intidx_[l] : -1; });
@@ -991,8 +1003,7 @@ void LevelSolver::initialize() {
   }
   fine("A21 count / prefix / fill + halo plans");
   lap("A12/A21 + halo plans");
-  // the pattern of the level matrix goes to the device first: the classes build their entry source lists from it there
-  d_krow_ = dev::upload(K_.rowptr); d_kcol_ = dev::upload(K_.col);
+  // (the pattern of the level matrix is on the device already: the classes build their entry source lists from it there)
   for (auto& cp : cls_) { cp->lu.d_krow = d_krow_; cp->lu.d_kcol = d_kcol_; }
   build_schur_setup();
   lap("Schur setup + uploads");
@@ -1004,8 +1015,6 @@ void LevelSolver::initialize() {
   d_t2_ = (double*)dev::alloc((size_t)std::max(n2_ + ngs_, 1) * sizeof(double));
   d_y2_ = (double*)dev::alloc((size_t)std::max(n2_, 1) * sizeof(double));
   d_yb_ = (double*)dev::alloc((size_t)std::max(n2_, 1) * sizeof(double));
-  d_a12_row_ = dev::upload(a12_row_); d_a12_col_ = dev::upload(a12_col_); d_a12_src_ = dev::upload(a12_src_);
-  d_a21_row_ = dev::upload(a21_row_); d_a21_col_ = dev::upload(a21_col_); d_a21_src_ = dev::upload(a21_src_);
   d_a12_val_ = (double*)dev::alloc(std::max<size_t>(1, a12_col_.size()) * sizeof(double));
   d_a21_val_ = (double*)dev::alloc(std::max<size_t>(1, a21_col_.size()) * sizeof(double));
   d_flag_ = (int32_t*)dev::alloc(sizeof(int32_t));
@@ -1411,6 +1420,8 @@ void LevelSolver::build_schur_setup() {
   // ---- pull lists.  Entries (row, column gid, source position) are bucketed by row with a counting pass,
   // packed as (column gid << 33 | source) and sorted row by row in parallel.
   HYMLS_CHECK(ext_total_ < ((int64_t)1 << 33), -2, "extraction buffer too large for the packed pull keys");
+  const size_t ext_bytes = (size_t)std::max<int64_t>(1, ext_total_) * sizeof(double);
+  std::unique_ptr<AsyncAlloc> pre_ext(ext_bytes >= ((size_t)1 << 30) ? new AsyncAlloc(ext_bytes) : nullptr);   // (see AsyncAlloc)
   std::vector<int64_t> rcount;
   rawvec<uint64_t> keys;
   std::vector<int64_t> rfill;
@@ -1648,7 +1659,7 @@ void LevelSolver::build_schur_setup() {
   }
   red_.val.resize(red_.col.size());             // (written by every Compute before it is read)
   d_red_val_ = (double*)dev::alloc(std::max<size_t>(1, red_.col.size()) * sizeof(double));
-  d_ext_ = (double*)dev::alloc(std::max<int64_t>(1, ext_total_) * sizeof(double));
+  d_ext_ = (double*)(pre_ext ? pre_ext->take() : dev::alloc(ext_bytes));
   for (auto& cp : cls_) {
     Cls& C = *cp;
     C.d_pick = dev::upload(C.pick);
@@ -1749,7 +1760,7 @@ void LevelSolver::set_values(const vvec& val) {
     return;
   }
   HYMLS_CHECK(val.size() == K_.val.size(), -2, "SetMatrix: pattern changed");
-  K_.val = val;
+  parallel_memcpy(K_.val.data(), val.data(), val.size() * sizeof(double));
 }
 
 // the reduced matrix of all ranks: every rank contributes the rows it owns; rows in rank order,

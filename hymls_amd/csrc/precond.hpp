@@ -7,6 +7,8 @@
 // work of Compute/ApplyInverse runs in the kernels behind device.hpp.
 #pragma once
 #include <memory>
+#include <thread>
+#include <exception>
 #include "common.hpp"
 #include "partition.hpp"
 #include "symbolic.hpp"
@@ -29,8 +31,39 @@ struct ApplyStats {
   double flops_factor = 0, flops_blocks = 0, flops_transform = 0;
 };
 
+// A device allocation made on a helper thread while the setup thread goes on: a hipMalloc of tens of GiB takes about 30 ms per
+// GiB (the driver clears the memory) -- 1.2 s for the factors and the extraction buffer of a 256^3 run, which now passes
+// while the host builds its tables.
+struct AsyncAlloc {
+  std::thread th;
+  void* p = nullptr;
+  size_t bytes = 0;
+  std::exception_ptr err;
+  explicit AsyncAlloc(size_t n) : bytes(n) {
+    dev::Context* c = dev::current();
+    th = std::thread([this, c] {
+      try { dev::bind(c); p = dev::alloc(bytes); dev::bind(nullptr); } catch (...) { err = std::current_exception(); }
+    });
+  }
+  void* take() {      // the allocation (the caller owns it from here on)
+    if (th.joinable()) th.join();
+    if (err) std::rethrow_exception(err);
+    void* q = p;
+    p = nullptr;
+    return q;
+  }
+  ~AsyncAlloc() {
+    if (th.joinable()) th.join();
+    if (p) dev::free(p);
+  }
+  AsyncAlloc(const AsyncAlloc&) = delete;
+  AsyncAlloc& operator=(const AsyncAlloc&) = delete;
+};
+
 // batched multifrontal LU of one pattern class, resident on the device
 struct BatchedLU {
+  std::unique_ptr<AsyncAlloc> pre_factor;   // factor storage requested ahead of upload() (see AsyncAlloc)
+  static size_t factor_bytes(int64_t nb, int64_t factor_size) { return (size_t)std::max<int64_t>(1, nb * factor_size) * sizeof(double); }
   ClassPlan plan;
   ivec members;                 // caller-defined ids (level subdomain ids)
   ivec h_xoff;
@@ -167,7 +200,7 @@ class LevelSolver : public Operator {
   ivec required_gids() const;           // rows this rank must be given: interiors + separators of its subdomains
   // K over local nodes: the first nrows nodes have rows (any superset of required_gids()), the others are
   // ghost columns; on one rank simply the whole matrix
-  void set_rows(Csr K, ivec gids, dvec tv, int32_t nrows);
+  void set_rows(const Csr& K, const ivec& gids, const dvec& tv, int32_t nrows);
   void initialize();
   void compute();                       // uses the host values of K (uploads them)
   void set_values(const vvec& val);     // SetMatrix with unchanged pattern
@@ -286,7 +319,8 @@ class LevelSolver : public Operator {
   int32_t* d_inperm_ = nullptr;
   double *d_z_ = nullptr, *d_t1_ = nullptr, *d_t2_ = nullptr, *d_y2_ = nullptr;
   // A12 / A21
-  ivec a12_row_, a12_col_, a12_src_, a21_row_, a21_col_, a21_src_;
+  ivec a12_row_, a21_row_;
+  cvec a12_col_, a12_src_, a21_col_, a21_src_;   // (host copies of the device tables)
   int32_t *d_a12_row_ = nullptr, *d_a12_col_ = nullptr, *d_a12_src_ = nullptr;
   int32_t *d_a21_row_ = nullptr, *d_a21_col_ = nullptr, *d_a21_src_ = nullptr;
   double *d_a12_val_ = nullptr, *d_a21_val_ = nullptr;

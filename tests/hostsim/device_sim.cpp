@@ -23,6 +23,7 @@ namespace dev {
 struct Context { int device; };
 Context* create_context(int device) { return new Context{device}; }
 void bind(Context*) {}
+Context* current() { return nullptr; }
 void destroy_context(Context* c) { delete c; }
 void* stream() { return nullptr; }
 const double* zeros16() { static const double z[16] = {0}; return z; }
@@ -79,6 +80,27 @@ void spmv(int32_t nrows, const int32_t* rp, const int32_t* col, const double* va
 }
 void pull_sum(int64_t n, const int64_t* ptr, const int64_t* idx, const double* in, double* out) {
   for (int64_t e = 0; e < n; e++) { double s = 0; for (int64_t t = ptr[e]; t < ptr[e + 1]; t++) s += in[idx[t]]; out[e] = s; }
+}
+static inline int32_t offdiag_target(int32_t c, const int32_t* ta, const int32_t* tb, const int32_t* excl) {
+  return ta[c] >= 0 ? ta[c] : ((tb && excl[c] < 0) ? tb[c] : -1);
+}
+void offdiag_count(int64_t nrows, const int32_t* rows, const int32_t* krow, const int32_t* kcol, const int32_t* ta, const int32_t* tb,
+                   const int32_t* excl, int32_t* count) {
+  for (int64_t t = 0; t < nrows; t++) {
+    int32_t o = 0;
+    for (int32_t e = krow[rows[t]]; e < krow[rows[t] + 1]; e++) o += offdiag_target(kcol[e], ta, tb, excl) >= 0;
+    count[t + 1] = o;
+  }
+}
+void offdiag_fill(int64_t nrows, const int32_t* rows, const int32_t* krow, const int32_t* kcol, const int32_t* ta, const int32_t* tb,
+                  const int32_t* excl, const int32_t* rowptr, int32_t* col, int32_t* src) {
+  for (int64_t t = 0; t < nrows; t++) {
+    int32_t o = rowptr[t];
+    for (int32_t e = krow[rows[t]]; e < krow[rows[t] + 1]; e++) {
+      const int32_t tg = offdiag_target(kcol[e], ta, tb, excl);
+      if (tg >= 0) { col[o] = tg; src[o] = e; o++; }
+    }
+  }
 }
 void member_sources(int32_t nb, int32_t next, int32_t nent, const int32_t* ext, const int32_t* ent_row, const int32_t* ent_col,
                     const int32_t* krow, const int32_t* kcol, int32_t* src, int32_t* flag) {

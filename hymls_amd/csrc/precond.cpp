@@ -103,6 +103,25 @@ BatchedLU::~BatchedLU() {
   for (void* p : owned) dev::free(p);
 }
 
+// members per factorisation pass and the doubles of frontal scratch / separator blocks / pivot-piece workspace a pass borrows
+// from the stream's arena (plan-only: known right after the symbolic analysis, so that the arenas can be requested early)
+void BatchedLU::plan_scratch(int64_t budget, bool with_sblock) {
+  const int nb = (int)members.size();
+  const int64_t per = plan.scratch_size + (with_sblock ? (int64_t)plan.nS * plan.nS : 0);
+  chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nb, budget / std::max<int64_t>(per, 1)));
+  scratch_need_ = std::max<int64_t>(1, (int64_t)chunk * plan.scratch_size);
+  sblock_need_ = with_sblock ? std::max<int64_t>(1, (int64_t)chunk * plan.nS * plan.nS) : 0;
+  bool any_wide = false;
+  for (auto& L : plan.fwide_levels) any_wide |= !L.empty();
+  batch.tmp_stride = 0; tmp_need_ = 0;
+  if (any_wide) {
+    // pivot-piece workspace of the multi-workgroup factorisation
+    const int64_t np = (plan.max_w + dev::PIECE - 1) / dev::PIECE;
+    batch.tmp_stride = np * 2 * dev::PIECE * dev::PIECE + 2LL * plan.max_w * dev::PIECE;
+    tmp_need_ = (int64_t)chunk * batch.tmp_stride;
+  }
+}
+
 void BatchedLU::upload(int64_t budget, bool with_sblock) {
   const int nb = (int)members.size();
   nent = (int32_t)plan.ent_id.size();
@@ -152,8 +171,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   }
   for (auto& L : plan.levels) d_lists.push_back(keep(dev::upload(L)));
   for (auto& L : plan.flevels) d_flists.push_back(keep(dev::upload(L)));
-  const int64_t per = plan.scratch_size + (with_sblock ? (int64_t)plan.nS * plan.nS : 0);
-  chunk = (int32_t)std::max<int64_t>(1, std::min<int64_t>(nb, budget / std::max<int64_t>(per, 1)));
+  plan_scratch(budget, with_sblock);
   batch.nb = nb;
   if (!h_ext.empty()) {
     HYMLS_CHECK(d_krow && d_kcol && (int64_t)h_ent_row.size() == nent && (int64_t)h_ext.size() == (int64_t)nb * n_ext, -3,
@@ -178,9 +196,7 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   const size_t fbytes = factor_bytes(nb, plan.factor_size);
   batch.factor = (double*)keep(pre_factor && pre_factor->bytes == fbytes ? pre_factor->take() : dev::alloc(fbytes));
   pre_factor.reset();
-  // frontal scratch / separator blocks / pivot workspace are borrowed from the shared arena at factor time
-  scratch_need_ = std::max<int64_t>(1, (int64_t)chunk * plan.scratch_size);
-  sblock_need_ = with_sblock ? std::max<int64_t>(1, (int64_t)chunk * plan.nS * plan.nS) : 0;
+  // frontal scratch / separator blocks / pivot workspace are borrowed from the shared arena at factor time (plan_scratch)
   batch.scratch = nullptr; batch.sblock = nullptr;
   batch.contrib = (double*)keep(dev::alloc(std::max<int64_t>(1, (int64_t)contrib_nv * nb * plan.contrib_size) * sizeof(double)));
   batch.flag = (int32_t*)keep(dev::alloc(4 * sizeof(int32_t)));   // [flag bits | pad | largest growth factor (double bits)]
@@ -189,13 +205,8 @@ void BatchedLU::upload(int64_t budget, bool with_sblock) {
   bool any_big = false, any_wide = false;
   for (auto& L : plan.big_levels) any_big |= !L.empty();
   for (auto& L : plan.fwide_levels) any_wide |= !L.empty();
-  batch.tmp = nullptr; batch.tmp_stride = 0; batch.swork = nullptr; batch.swork_stride = 0;
-  if (any_wide) {
-    // pivot-piece workspace of the multi-workgroup factorisation
-    const int64_t np = (plan.max_w + dev::PIECE - 1) / dev::PIECE;
-    batch.tmp_stride = np * 2 * dev::PIECE * dev::PIECE + 2LL * plan.max_w * dev::PIECE;
-    tmp_need_ = (int64_t)chunk * batch.tmp_stride;
-  }
+  batch.tmp = nullptr; batch.swork = nullptr; batch.swork_stride = 0;
+  (void)any_wide;
   if (any_big) {
     int64_t part_max = 0;
     for (auto& L : plan.big_levels) {
@@ -919,6 +930,7 @@ void LevelSolver::initialize() {
     const size_t fb = BatchedLU::factor_bytes((int64_t)cp->lu.members.size(), cp->lu.plan.factor_size);
     if (fb >= ((size_t)1 << 30) && !cp->lu.pre_factor) cp->lu.pre_factor.reset(new AsyncAlloc(fb));
   }
+  request_arenas();
   lap("pattern classes + plans");
   fine.t = wall();
   // owned rows = layout of the vectors handed to apply_inverse (order of the rows as they were given)
@@ -1859,6 +1871,38 @@ void LevelSolver::build_handoff(const ivec& next_owned) {
   d_nsol_ = (double*)dev::alloc(std::max<size_t>(1, next_owned.size()) * nvec_alloc_ * sizeof(double));
 }
 
+// which streams the factorisation of this level uses: the classes of the coarser levels round robin over the side streams,
+// the chunks of the finest level alternating between chunk_streams of them
+void LevelSolver::stream_plan(bool& side, int& chunk_streams) const {
+  const bool no_side = std::getenv("HYMLS_MI_NO_SIDE_STREAMS") != nullptr;
+  side = level_ >= 1 && cls_.size() > 1 && !no_side;
+  static const int chunk_streams_env = std::getenv("HYMLS_MI_CHUNK_STREAMS") ? std::atoi(std::getenv("HYMLS_MI_CHUNK_STREAMS")) : 2;
+  chunk_streams = level_ == 0 && !no_side ? std::max(0, std::min(chunk_streams_env, dev::side_streams())) : 0;
+}
+
+// the scratch arenas the first Compute will want, requested on helper threads as soon as the plans are known (their
+// allocation takes a second at 256^3, see AsyncAlloc)
+void LevelSolver::request_arenas() {
+  bool side = false;
+  int chunk_streams = 0;
+  stream_plan(side, chunk_streams);
+  std::vector<size_t> need(dev::NSIDE + 1, 0);
+  int64_t chunk_id = 0;
+  for (size_t c = 0; c < cls_.size(); c++) {
+    BatchedLU& lu = cls_[c]->lu;
+    lu.plan_scratch(SCRATCH_BUDGET, true);
+    const size_t bytes = (size_t)(lu.scratch_need_ + lu.sblock_need_ + lu.tmp_need_) * sizeof(double);
+    const int nb = (int)lu.members.size();
+    for (int b0 = 0; b0 < nb; b0 += lu.chunk) {
+      const int k = chunk_streams ? 1 + (int)(chunk_id++ % chunk_streams) : (side ? 1 + (int)(c % dev::side_streams()) : 0);
+      need[k] = std::max(need[k], bytes);
+    }
+  }
+  pre_arena_.clear();
+  for (int k = 0; k <= dev::NSIDE; k++)
+    if (need[k] >= ((size_t)1 << 30) && need[k] > dev::scratch_capacity(k)) pre_arena_.emplace_back(k, std::unique_ptr<AsyncAlloc>(new AsyncAlloc(need[k])));
+}
+
 void LevelSolver::compute() {
   HYMLS_CHECK(initialized_, -1, "level not initialized");
   dev::Range range("Preconditioner", level_ + 1, "Compute");
@@ -1879,10 +1923,12 @@ void LevelSolver::compute() {
   // The finest level has a few classes with thousands of members: there the CHUNKS of a class alternate between two side
   // streams, so that the narrow launches at the top of one chunk's elimination tree overlap the leaf launches of the next
   // (HYMLS_MI_CHUNK_STREAMS = 0 switches that off, 1..NSIDE sets the number of streams).
-  const bool no_side = std::getenv("HYMLS_MI_NO_SIDE_STREAMS") != nullptr;
-  const bool side = level_ >= 1 && cls_.size() > 1 && !no_side;
-  static const int chunk_streams_env = std::getenv("HYMLS_MI_CHUNK_STREAMS") ? std::atoi(std::getenv("HYMLS_MI_CHUNK_STREAMS")) : 2;
-  const int chunk_streams = level_ == 0 && !no_side ? std::max(0, std::min(chunk_streams_env, dev::side_streams())) : 0;
+  bool side = false;
+  int chunk_streams = 0;
+  stream_plan(side, chunk_streams);
+  // scratch arenas requested during Initialize (see AsyncAlloc) go to their streams now
+  for (auto& pa : pre_arena_) dev::adopt_scratch(pa.first, pa.second->take(), pa.second->bytes);
+  pre_arena_.clear();
   struct MainStreamGuard { ~MainStreamGuard() { try { dev::use_stream(0); } catch (...) {} } } back_to_main;   // also when a launch throws
   for (auto& cp : cls_) dev::zero(cp->lu.batch.flag, 4 * sizeof(int32_t));   // (on the main stream, before any side stream starts)
   // (the subdomain factorisations and what is kept of the Schur complement come out of the same launches here: one range)

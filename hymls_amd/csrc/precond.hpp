@@ -91,6 +91,7 @@ struct BatchedLU {
   bool packed = false;            // panels repacked after the factorisation (classes solved by the fused kernel)
   int contrib_nv = 1;             // columns of contribution scratch (several right-hand sides in the task kernels)
   ~BatchedLU();
+  void plan_scratch(int64_t scratch_budget_doubles, bool with_sblock);
   void upload(int64_t scratch_budget_doubles, bool with_sblock);
   // numeric factorisation of members [b0,b0+nbc) (scratch slots 0..nbc-1)
   void factor_chunk(const double* kval, int32_t b0, int32_t nbc, bool spread_wide = false);
@@ -201,6 +202,9 @@ class LevelSolver : public Operator {
   // K over local nodes: the first nrows nodes have rows (any superset of required_gids()), the others are
   // ghost columns; on one rank simply the whole matrix
   void set_rows(const Csr& K, const ivec& gids, const dvec& tv, int32_t nrows);
+  void stream_plan(bool& side, int& chunk_streams) const;
+  void request_arenas();
+  std::vector<std::pair<int, std::unique_ptr<AsyncAlloc>>> pre_arena_;   // (stream, allocation under way)
   void initialize();
   void compute();                       // uses the host values of K (uploads them)
   void set_values(const vvec& val);     // SetMatrix with unchanged pattern

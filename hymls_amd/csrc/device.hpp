@@ -32,10 +32,6 @@ size_t mem_free();
 // process-wide setup scratch (frontal matrices, separator blocks, pivot-piece workspace): factorisations run one
 // after the other on the stream, so every batch borrows the same arena; grown on demand (synchronises when it grows)
 void* shared_scratch(size_t bytes);
-// capacity of the scratch arena of stream k (0 = main, 1 .. = side streams); adopt_scratch hands an allocation made elsewhere
-// (AsyncAlloc) to stream k's arena if it is larger than what is there, and frees it otherwise
-size_t scratch_capacity(int k);
-void adopt_scratch(int k, void* p, size_t bytes);
 // side streams for independent setup work (the many small batches of the coarser levels would otherwise run one tiny
 // launch after the other): fork_streams() makes the side streams wait for the main one, use_stream(k) directs every
 // following launch / copy / scratch request to stream k (0 = main, 1..NSIDE), join_streams() makes the main stream wait

@@ -173,16 +173,6 @@ void* shared_scratch(size_t bytes) {
   }
   return c.arena[k];
 }
-size_t scratch_capacity(int k) { return (k >= 0 && k <= NSIDE) ? ctx().arena_cap[k] : 0; }
-void adopt_scratch(int k, void* p, size_t bytes) {
-  Context& c = ctx();
-  if (!p) return;
-  if (k < 0 || k > NSIDE || bytes <= c.arena_cap[k]) { (void)hipFree(p); return; }
-  HIP_CHECK(hipDeviceSynchronize());          // (nothing may still use the arena that goes away)
-  if (c.arena[k]) (void)hipFree(c.arena[k]);
-  c.arena[k] = p;
-  c.arena_cap[k] = bytes;
-}
 const double* zeros16() {
   Context& c = ctx();
   if (!c.zeros) { c.zeros = (double*)alloc(16 * sizeof(double)); zero(c.zeros, 16 * sizeof(double)); }

@@ -930,7 +930,6 @@ void LevelSolver::initialize() {
     const size_t fb = BatchedLU::factor_bytes((int64_t)cp->lu.members.size(), cp->lu.plan.factor_size);
     if (fb >= ((size_t)1 << 30) && !cp->lu.pre_factor) cp->lu.pre_factor.reset(new AsyncAlloc(fb));
   }
-  request_arenas();
   lap("pattern classes + plans");
   fine.t = wall();
   // owned rows = layout of the vectors handed to apply_inverse (order of the rows as they were given)
@@ -1086,6 +1085,95 @@ void LevelSolver::build_classes() {
   const bool device_src = unsorted == 0 && !std::getenv("HYMLS_MI_HOST_SOURCE_LISTS");
   static std::atomic<long long> tprof[6];
   auto tnow = []() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  // coordinates of the interior nodes relative to the subdomain (parity of the corner kept: staggered grids)
+  auto rel_coords = [&](int s, ivec& coord) {
+    const Subdomain& S = hm_.sd[s];
+    const int nI = (int)S.interior.size();
+    coord.resize(3 * (size_t)nI);
+    int32_t mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
+    int spos[3] = {0, 0, 0};
+    const bool wraps = p_.perio[0] || p_.perio[1] || p_.perio[2];
+    if (wraps) sd_position(p_, s, spos[0], spos[1], spos[2]);
+    const int nn[3] = {p_.nx, p_.ny, p_.nz}, ss[3] = {p_.sx, p_.sy, p_.sz};
+    for (int i = 0; i < nI; i++) {
+      int32_t* cc = &coord[3 * (size_t)i];
+      gid_coord(p_, S.interior[i], cc);
+      // a subdomain that reaches across a periodic boundary: the image next to the subdomain's reference corner (every
+      // node lies within [pos - s - 1, pos + s + 1]), so that relative coordinates are those of an inner subdomain
+      if (wraps) for (int a = 0; a < 3; a++) if (p_.perio[a]) {
+        const int lo = 2 * (spos[a] - ss[a] - 1), per2 = 2 * nn[a];
+        cc[a] = lo + (((cc[a] - lo) % per2) + per2) % per2;
+      }
+      for (int a = 0; a < 3; a++) mn[a] = std::min(mn[a], cc[a]);
+    }
+    for (int i = 0; i < nI; i++) for (int a = 0; a < 3; a++) coord[3 * (size_t)i + a] -= mn[a] & ~1;
+  };
+  // ---- Shortcut for the thousands of subdomains that are translates of one another (69 696 subdomains, 54 classes at 256^3):
+  // a 128-bit signature of everything the extended local pattern is a function of -- the node list relative to its first
+  // node, a hash of every row of the level matrix relative to its row number (columns - row, diagonal zero or not), the
+  // subdomains listing every separator node relative to this subdomain (the A22 multiplicities are intersections of those
+  // lists), group sizes / types / links, relative coordinates.  A subdomain whose signature is known takes the class without
+  // its pattern being built (the scan of its 1 335 matrix rows with a hash probe per entry); every class still has a fully
+  // built, fully compared representative.  HYMLS_MI_VERIFY_CLASSES=1 builds every pattern nevertheless and checks that the
+  // shortcut agrees (tests); HYMLS_MI_NO_FAST_CLASSES switches it off.
+  struct Sig { uint64_t a, b; bool operator==(const Sig& o) const { return a == o.a && b == o.b; } };
+  struct SigHash { size_t operator()(const Sig& q) const { return (size_t)(q.a ^ (q.b * 0x9E3779B97F4A7C15ULL)); } };
+  struct SigMix {
+    uint64_t a = 0x243F6A8885A308D3ULL, b = 0x13198A2E03707344ULL;
+    void add(uint64_t w) {
+      a = (a ^ w) * 0x9E3779B97F4A7C15ULL; a ^= a >> 29;
+      b ^= w * 0xC2B2AE3D27D4EB4FULL; b = (b << 31) | (b >> 33); b *= 0x165667B19E3779F9ULL;
+    }
+  };
+  const bool fast_classes = device_src && !std::getenv("HYMLS_MI_NO_FAST_CLASSES");
+  const bool verify_classes = std::getenv("HYMLS_MI_VERIFY_CLASSES") != nullptr;
+  std::vector<uint64_t> rowh;
+  if (fast_classes) {
+    rowh.resize((size_t)K_.n);
+    parallel_for(K_.n, [&](int64_t r) {
+      SigMix m;
+      m.add((uint64_t)(K_.rowptr[r + 1] - K_.rowptr[r]));
+      uint64_t dz = 1;    // no non-zero diagonal entry
+      for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
+        m.add((uint64_t)(uint32_t)(K_.col[e] - (int32_t)r));
+        if (K_.col[e] == r && K_.val[e] != 0.0) dz = 0;
+      }
+      m.add(dz);
+      rowh[(size_t)r] = m.a ^ (m.b << 1);
+    }, 1 << 12);
+  }
+  std::unordered_map<Sig, int, SigHash> sigtable;
+  std::atomic<long long> n_fast{0};
+  auto signature = [&](int s, ivec& ext, Sig& sig) -> bool {
+    const Subdomain& S = hm_.sd[s];
+    const int nI = (int)S.interior.size();
+    ext.clear();
+    ext.reserve(nI + S.num_sep());
+    for (int32_t g : S.interior) ext.push_back(g2l_[g]);
+    SigMix m;
+    m.add((uint64_t)nI); m.add((uint64_t)S.num_sep()); m.add((uint64_t)S.groups.size());
+    for (auto& g : S.groups) {
+      for (int32_t x : g.nodes) ext.push_back(g2l_[x]);
+      m.add(((uint64_t)(uint32_t)g.type << 32) | (uint64_t)g.nodes.size());
+    }
+    for (auto& L : S.linked) { m.add(0xFFFFFFFFFFFFFFF9ULL); for (int gi : L) m.add((uint64_t)gi); }
+    if (ext.empty()) return false;
+    const int ne = (int)ext.size();
+    for (int i = 0; i < ne; i++) if (!(ext[i] >= 0 && ext[i] < nrows_)) return false;     // (the full build reports what is wrong)
+    const int32_t e0 = ext[0];
+    for (int i = 0; i < ne; i++) { m.add((uint64_t)(uint32_t)(ext[i] - e0)); m.add(rowh[(size_t)ext[i]]); }
+    for (int i = nI; i < ne; i++) {
+      const int k = pos2_[ext[i]];
+      if (k < 0) return false;
+      m.add((uint64_t)(cnt[k + 1] - cnt[k]));
+      for (int t = cnt[k]; t < cnt[k + 1]; t++) m.add((uint64_t)(uint32_t)(sdl[t] - s));
+    }
+    ivec coord;
+    rel_coords(s, coord);
+    for (int32_t c : coord) m.add((uint64_t)(uint32_t)c);
+    sig = Sig{m.a, m.b};
+    return true;
+  };
   auto build_pattern = [&](int s, SdPat& out) {
     long long tq = tnow();
     auto lapq = [&](int k) { const long long t = tnow(); tprof[k] += t - tq; tq = t; };
@@ -1143,25 +1231,7 @@ void LevelSolver::build_classes() {
       lp.rowptr[i + 1] = (int32_t)lp.col.size();
     }
     lapq(1);
-    // relative coordinates
-    lp.coord.resize(3 * (size_t)lp.nI);
-    int32_t mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX};
-    int spos[3] = {0, 0, 0};
-    const bool wraps = p_.perio[0] || p_.perio[1] || p_.perio[2];
-    if (wraps) sd_position(p_, s, spos[0], spos[1], spos[2]);
-    const int nn[3] = {p_.nx, p_.ny, p_.nz}, ss[3] = {p_.sx, p_.sy, p_.sz};
-    for (int i = 0; i < lp.nI; i++) {
-      int32_t* cc = &lp.coord[3 * (size_t)i];
-      gid_coord(p_, S.interior[i], cc);
-      // a subdomain that reaches across a periodic boundary: the image next to the subdomain's reference corner (every
-      // node lies within [pos - s - 1, pos + s + 1]), so that relative coordinates are those of an inner subdomain
-      if (wraps) for (int a = 0; a < 3; a++) if (p_.perio[a]) {
-        const int lo = 2 * (spos[a] - ss[a] - 1), per2 = 2 * nn[a];
-        cc[a] = lo + (((cc[a] - lo) % per2) + per2) % per2;
-      }
-      for (int a = 0; a < 3; a++) mn[a] = std::min(mn[a], cc[a]);
-    }
-    for (int i = 0; i < lp.nI; i++) for (int a = 0; a < 3; a++) lp.coord[3 * (size_t)i + a] -= mn[a] & ~1;
+    rel_coords(s, lp.coord);
     Hasher H;
     H.add(&lp.nI, 4); H.add(&lp.nS, 4);
     H.addv(lp.rowptr); H.addv(lp.col); H.addv(lp.zero_diag); H.addv(lp.coord); H.addv(out.mult);
@@ -1188,6 +1258,21 @@ void LevelSolver::build_classes() {
     parallel_for(64, [&](int64_t) {
       for (int64_t k = next.fetch_add(1); k < nmine; k = next.fetch_add(1)) {
         const int s = my_sds_[k];
+        Sig sig{0, 0};
+        ivec ext_fast;
+        int cid_fast = -1;
+        const bool have_sig = fast_classes && signature(s, ext_fast, sig);
+        if (have_sig) {
+          std::lock_guard<std::mutex> lk(mu);
+          auto it = sigtable.find(sig);
+          if (it != sigtable.end()) cid_fast = it->second;
+        }
+        if (cid_fast >= 0 && !verify_classes) {
+          sd_cls_[s] = cid_fast;
+          sd_src[s].swap(ext_fast);
+          n_fast++;
+          continue;
+        }
         SdPat Pt;
         build_pattern(s, Pt);
         if (!Pt.err.empty()) {
@@ -1218,6 +1303,10 @@ void LevelSolver::build_classes() {
             is_new = true;
           }
           rep = cls_[cid].get();     // (the vector may grow under another thread's hands: the object itself stays put)
+          if (have_sig) {
+            auto ins = sigtable.emplace(sig, cid);
+            if (ins.first->second != cid || (cid_fast >= 0 && cid_fast != cid)) mismatch = 2;   // (verification mode, or two builders of one signature)
+          }
         }
         if (!is_new) {
           const Cls& C = *rep;
@@ -1231,7 +1320,10 @@ void LevelSolver::build_classes() {
       }
     }, 1);
     HYMLS_CHECK(err_k < 0, err_msg.find("decouple") != std::string::npos ? -2 : -3, err_msg);
+    HYMLS_CHECK(mismatch != 2, -3, "pattern class shortcut: one signature, two different extended patterns");
     HYMLS_CHECK(mismatch == 0, -3, "two different subdomain patterns share one 64-bit hash");
+    if (std::getenv("HYMLS_MI_PATTERN_PROF"))
+      std::fprintf(stderr, "[hymls_mi] pattern classes: %lld of %lld subdomains classified by signature\n", (long long)n_fast, (long long)nmine);
     // new classes in the order of their first member; members in subdomain order
     const int nnew = (int)(cls_.size() - first_new);
     ivec new_id(nnew, -1);
@@ -1880,29 +1972,9 @@ void LevelSolver::stream_plan(bool& side, int& chunk_streams) const {
   chunk_streams = level_ == 0 && !no_side ? std::max(0, std::min(chunk_streams_env, dev::side_streams())) : 0;
 }
 
-// the scratch arenas the first Compute will want, requested on helper threads as soon as the plans are known (their
-// allocation takes a second at 256^3, see AsyncAlloc)
-void LevelSolver::request_arenas() {
-  bool side = false;
-  int chunk_streams = 0;
-  stream_plan(side, chunk_streams);
-  std::vector<size_t> need(dev::NSIDE + 1, 0);
-  int64_t chunk_id = 0;
-  for (size_t c = 0; c < cls_.size(); c++) {
-    BatchedLU& lu = cls_[c]->lu;
-    lu.plan_scratch(SCRATCH_BUDGET, true);
-    const size_t bytes = (size_t)(lu.scratch_need_ + lu.sblock_need_ + lu.tmp_need_) * sizeof(double);
-    const int nb = (int)lu.members.size();
-    for (int b0 = 0; b0 < nb; b0 += lu.chunk) {
-      const int k = chunk_streams ? 1 + (int)(chunk_id++ % chunk_streams) : (side ? 1 + (int)(c % dev::side_streams()) : 0);
-      need[k] = std::max(need[k], bytes);
-    }
-  }
-  pre_arena_.clear();
-  for (int k = 0; k <= dev::NSIDE; k++)
-    if (need[k] >= ((size_t)1 << 30) && need[k] > dev::scratch_capacity(k)) pre_arena_.emplace_back(k, std::unique_ptr<AsyncAlloc>(new AsyncAlloc(need[k])));
-}
-
+// (Measured and dropped, gpurun_out/r3ag: requesting the scratch arenas of the first Compute -- 6 - 8 GiB per stream, 1.4 s of
+// hipMalloc -- on helper threads during Initialize as well.  Together with the factor arrays that is 50 GiB for the driver to
+// clear, and every HIP call of the setup thread queues behind it: A12 / A21 0.46 -> 1.7 s, pull lists 0.63 -> 1.0 s.)
 void LevelSolver::compute() {
   HYMLS_CHECK(initialized_, -1, "level not initialized");
   dev::Range range("Preconditioner", level_ + 1, "Compute");
@@ -1926,9 +1998,6 @@ void LevelSolver::compute() {
   bool side = false;
   int chunk_streams = 0;
   stream_plan(side, chunk_streams);
-  // scratch arenas requested during Initialize (see AsyncAlloc) go to their streams now
-  for (auto& pa : pre_arena_) dev::adopt_scratch(pa.first, pa.second->take(), pa.second->bytes);
-  pre_arena_.clear();
   struct MainStreamGuard { ~MainStreamGuard() { try { dev::use_stream(0); } catch (...) {} } } back_to_main;   // also when a launch throws
   for (auto& cp : cls_) dev::zero(cp->lu.batch.flag, 4 * sizeof(int32_t));   // (on the main stream, before any side stream starts)
   // (the subdomain factorisations and what is kept of the Schur complement come out of the same launches here: one range)

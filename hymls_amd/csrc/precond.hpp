@@ -203,8 +203,6 @@ class LevelSolver : public Operator {
   // ghost columns; on one rank simply the whole matrix
   void set_rows(const Csr& K, const ivec& gids, const dvec& tv, int32_t nrows);
   void stream_plan(bool& side, int& chunk_streams) const;
-  void request_arenas();
-  std::vector<std::pair<int, std::unique_ptr<AsyncAlloc>>> pre_arena_;   // (stream, allocation under way)
   void initialize();
   void compute();                       // uses the host values of K (uploads them)
   void set_values(const vvec& val);     // SetMatrix with unchanged pattern

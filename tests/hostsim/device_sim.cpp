@@ -43,8 +43,6 @@ void* shared_scratch(size_t bytes) {
   if (bytes > g_arena_cap) { std::free(g_arena); g_arena = std::malloc(bytes); g_arena_cap = bytes; }
   return g_arena;
 }
-size_t scratch_capacity(int) { return g_arena_cap; }
-void adopt_scratch(int, void* p, size_t) { std::free(p); }
 size_t mem_free() { return (size_t)1 << 40; }
 // ranges: no profiler on the host; the log file is what the tests read
 static std::FILE* range_log() {

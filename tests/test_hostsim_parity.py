@@ -329,3 +329,56 @@ def test_recompute_keeps_the_coarse_plan_hostsim(hostsim_lib, eq, n, sx, levels,
     F = product_prec(A, tv, xml_params(eq, n, sx, levels, cx, "Skew Cartesian" if eq == "Stokes-C" else "Cartesian"), hostsim_lib)
     assert rel_diff(P.ApplyInverse(b), F.ApplyInverse(b)) < 1e-12
     assert P.NumInitialize() == 1 and P.NumCompute() == 3
+
+
+CLASS_CASES = [
+    # eq, n, sx, levels, cx, partitioner, extra
+    ("Laplace", 24, 4, 2, 2, "Cartesian", None),
+    ("Stokes-C", 16, 4, 0, -1, "Cartesian", None),
+    ("Stokes-C", 32, 8, 1, -1, "Skew Cartesian", None),
+    ("Stokes-C", 24, 4, 2, 2, "Skew Cartesian", None),
+    ("Stokes-C", 8, 4, 0, -1, "Skew Cartesian", {"x-periodic": True, "y-periodic": True, "z-periodic": True}),
+]
+
+
+@pytest.mark.parametrize("eq,n,sx,levels,cx,part,extra", CLASS_CASES)
+def test_pattern_class_shortcut_agrees_with_the_full_patterns(hostsim_lib, monkeypatch, capfd, eq, n, sx, levels, cx, part, extra):
+    """Initialize classifies a subdomain by a signature (node list relative to its first node, hashes of the matrix rows
+    relative to their row number, the subdomains listing every separator node, group structure, relative coordinates) and
+    builds the extended pattern only for the first subdomain of every signature (csrc/precond.cpp, build_classes).
+    HYMLS_MI_VERIFY_CLASSES builds every pattern nevertheless and fails with -3 if the shortcut would have chosen another
+    class; the results with the shortcut, with the verification and without the shortcut are the same bits."""
+    import hymls_amd
+    if eq == "Laplace":
+        K = hymls_amd.generate_problem("Laplace", n, n, n, lib=hostsim_lib)
+    else:
+        K = hymls_amd.generate_problem("Stokes", n, n, n, lib=hostsim_lib, periodic=(True, True, True) if extra else (False, False, False))
+    tv = hymls_amd.generate_testvector(*K, lib=hostsim_lib)
+    prm = xml_params(eq, n, sx, levels, cx, part)
+    if extra:
+        prm["Problem"].update(extra)
+    b = np.random.default_rng(5).uniform(-1, 1, K[0].size - 1)
+    out = []
+    for env in ({}, {"HYMLS_MI_VERIFY_CLASSES": "1"}, {"HYMLS_MI_NO_FAST_CLASSES": "1"}):
+        for k in ("HYMLS_MI_VERIFY_CLASSES", "HYMLS_MI_NO_FAST_CLASSES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("HYMLS_MI_PATTERN_PROF", "1")
+        P = hymls_amd.Preconditioner(K, prm, testVector=tv, lib=hostsim_lib)
+        assert P.Initialize() == 0
+        if extra:
+            # (periodic Stokes is singular without a border, tests/test_periodic.py: here only the classification runs)
+            x = np.asarray(P.level_sizes(), dtype=np.float64).ravel()
+        else:
+            assert P.Compute() == 0
+            x = P.ApplyInverse(b)
+        out.append(x)
+        err = capfd.readouterr().err
+        if not env:
+            import re
+            m = re.search(r"pattern classes: (\d+) of (\d+) subdomains classified by signature", err)
+            assert m, err[-500:]
+            if int(m.group(2)) >= 64:
+                assert int(m.group(1)) > 0          # the shortcut is actually taken where translates exist
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])

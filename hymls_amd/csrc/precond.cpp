@@ -925,11 +925,6 @@ void LevelSolver::initialize() {
   direct_schur_ = level_ >= p_.levels;
   lap("separator numbering");
   build_classes();
-  // the large factor arrays are requested now, on helper threads: the allocations pass while the tables below are built
-  for (auto& cp : cls_) {
-    const size_t fb = BatchedLU::factor_bytes((int64_t)cp->lu.members.size(), cp->lu.plan.factor_size);
-    if (fb >= ((size_t)1 << 30) && !cp->lu.pre_factor) cp->lu.pre_factor.reset(new AsyncAlloc(fb));
-  }
   lap("pattern classes + plans");
   fine.t = wall();
   // owned rows = layout of the vectors handed to apply_inverse (order of the rows as they were given)
@@ -1014,6 +1009,12 @@ void LevelSolver::initialize() {
   }
   fine("A21 count / prefix / fill + halo plans");
   lap("A12/A21 + halo plans");
+  // the large factor arrays are requested now, on helper threads: the allocations pass while the host builds the tables of
+  // the Schur set-up (not earlier: the device calls of the A12 / A21 step above would queue behind them)
+  for (auto& cp : cls_) {
+    const size_t fb = BatchedLU::factor_bytes((int64_t)cp->lu.members.size(), cp->lu.plan.factor_size);
+    if (fb >= ((size_t)1 << 30) && !cp->lu.pre_factor) cp->lu.pre_factor.reset(new AsyncAlloc(fb));
+  }
   // (the pattern of the level matrix is on the device already: the classes build their entry source lists from it there)
   for (auto& cp : cls_) { cp->lu.d_krow = d_krow_; cp->lu.d_kcol = d_kcol_; }
   build_schur_setup();
@@ -1078,10 +1079,33 @@ void LevelSolver::build_classes() {
   struct SdPat { LocalPattern lp; ivec src, ext, mult, lgptr, key_extra; uint64_t hash = 0; std::string err; };
   // rows of the level matrix with strictly ascending columns: the device finds the entries of every member itself
   // (dev::member_sources) from the members' node lists; otherwise the lists are built here, entry by entry
+  // (one pass over the matrix answers the question and leaves the row hashes of the class signatures below)
+  struct SigMix {
+    uint64_t a = 0x243F6A8885A308D3ULL, b = 0x13198A2E03707344ULL;
+    void add(uint64_t w) {
+      a = (a ^ w) * 0x9E3779B97F4A7C15ULL; a ^= a >> 29;
+      b ^= w * 0xC2B2AE3D27D4EB4FULL; b = (b << 31) | (b >> 33); b *= 0x165667B19E3779F9ULL;
+    }
+  };
+  const bool want_fast = !std::getenv("HYMLS_MI_NO_FAST_CLASSES") && !std::getenv("HYMLS_MI_HOST_SOURCE_LISTS");
+  std::vector<uint64_t> rowh;
+  if (want_fast) rowh.resize((size_t)K_.n);
   std::atomic<int> unsorted{0};
   parallel_for(K_.n, [&](int64_t r) {
-    for (int e = K_.rowptr[r] + 1; e < K_.rowptr[r + 1]; e++) if (K_.col[e] <= K_.col[e - 1]) { unsorted = 1; break; }
-  }, 1 << 14);
+    SigMix m;
+    m.add((uint64_t)(K_.rowptr[r + 1] - K_.rowptr[r]));
+    uint64_t dz = 1;    // no non-zero diagonal entry
+    bool bad = false;
+    for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
+      if (e > K_.rowptr[r] && K_.col[e] <= K_.col[e - 1]) bad = true;
+      if (want_fast) {
+        m.add((uint64_t)(uint32_t)(K_.col[e] - (int32_t)r));
+        if (K_.col[e] == r && K_.val[e] != 0.0) dz = 0;
+      }
+    }
+    if (bad) unsorted = 1;
+    if (want_fast) { m.add(dz); rowh[(size_t)r] = m.a ^ (m.b << 1); }
+  }, 1 << 12);
   const bool device_src = unsorted == 0 && !std::getenv("HYMLS_MI_HOST_SOURCE_LISTS");
   static std::atomic<long long> tprof[6];
   auto tnow = []() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1118,30 +1142,12 @@ void LevelSolver::build_classes() {
   // shortcut agrees (tests); HYMLS_MI_NO_FAST_CLASSES switches it off.
   struct Sig { uint64_t a, b; bool operator==(const Sig& o) const { return a == o.a && b == o.b; } };
   struct SigHash { size_t operator()(const Sig& q) const { return (size_t)(q.a ^ (q.b * 0x9E3779B97F4A7C15ULL)); } };
-  struct SigMix {
-    uint64_t a = 0x243F6A8885A308D3ULL, b = 0x13198A2E03707344ULL;
-    void add(uint64_t w) {
-      a = (a ^ w) * 0x9E3779B97F4A7C15ULL; a ^= a >> 29;
-      b ^= w * 0xC2B2AE3D27D4EB4FULL; b = (b << 31) | (b >> 33); b *= 0x165667B19E3779F9ULL;
-    }
-  };
-  const bool fast_classes = device_src && !std::getenv("HYMLS_MI_NO_FAST_CLASSES");
+  const bool fast_classes = device_src && want_fast;
   const bool verify_classes = std::getenv("HYMLS_MI_VERIFY_CLASSES") != nullptr;
-  std::vector<uint64_t> rowh;
-  if (fast_classes) {
-    rowh.resize((size_t)K_.n);
-    parallel_for(K_.n, [&](int64_t r) {
-      SigMix m;
-      m.add((uint64_t)(K_.rowptr[r + 1] - K_.rowptr[r]));
-      uint64_t dz = 1;    // no non-zero diagonal entry
-      for (int e = K_.rowptr[r]; e < K_.rowptr[r + 1]; e++) {
-        m.add((uint64_t)(uint32_t)(K_.col[e] - (int32_t)r));
-        if (K_.col[e] == r && K_.val[e] != 0.0) dz = 0;
-      }
-      m.add(dz);
-      rowh[(size_t)r] = m.a ^ (m.b << 1);
-    }, 1 << 12);
-  }
+  // relative coordinates follow from the relative node numbers when the grid is much wider than a subdomain (a difference of
+  // two gids then has one decomposition into (dx, dy, dz, dvar)); on small grids they are hashed explicitly
+  const bool coords_implied = p_.nx >= 4 * p_.sx + 8 && p_.ny >= 4 * p_.sy + 8 && (p_.nz == 1 || p_.nz >= 4 * p_.sz + 8) &&
+                              !(p_.perio[0] || p_.perio[1] || p_.perio[2]);
   std::unordered_map<Sig, int, SigHash> sigtable;
   std::atomic<long long> n_fast{0};
   auto signature = [&](int s, ivec& ext, Sig& sig) -> bool {
@@ -1168,9 +1174,16 @@ void LevelSolver::build_classes() {
       m.add((uint64_t)(cnt[k + 1] - cnt[k]));
       for (int t = cnt[k]; t < cnt[k + 1]; t++) m.add((uint64_t)(uint32_t)(sdl[t] - s));
     }
-    ivec coord;
-    rel_coords(s, coord);
-    for (int32_t c : coord) m.add((uint64_t)(uint32_t)c);
+    if (coords_implied && nI > 0) {
+      int32_t cc[3];
+      gid_coord(p_, S.interior[0], cc);      // parity of the corner (staggered grid)
+      m.add((uint64_t)((cc[0] & 1) | ((cc[1] & 1) << 1) | ((cc[2] & 1) << 2)));
+      m.add((uint64_t)(uint32_t)(S.interior[0] % p_.dof));
+    } else {
+      ivec coord;
+      rel_coords(s, coord);
+      for (int32_t c : coord) m.add((uint64_t)(uint32_t)c);
+    }
     sig = Sig{m.a, m.b};
     return true;
   };

@@ -41,7 +41,8 @@ constexpr int LEAF_SIZE = 24;
 constexpr int LEAF_SIZE_UPPER = 64;   // levels >= 1 (measured at 256^3: coarse phase 6.2 -> 5.7 ms; 48: 5.8, 96: 5.6)
 constexpr int MAX_WIDTH = 256;
 constexpr int MAX_WIDTH_COARSE = 256;  // wider supernodes take the piece-wise big-front path
-constexpr int LEAF_SIZE_COARSE = 64;
+constexpr int LEAF_SIZE_COARSE = 512; // last-level solver (measured on configs[1], 216 k unknowns, gpurun_out/r3aj + r3ak: coarse phase 2.40 ms at 64,
+                                      // 2.29 / 2.17 / 2.14 / 2.00 / 2.11 ms at 32 / 128 / 256 / 512 / 1024; the numeric Compute 0.98 -> 1.07 s)
 constexpr int64_t SCRATCH_BUDGET = 1LL << 30;  // doubles (8 GiB) of frontal scratch per pass
 
 }  // namespace
@@ -1034,7 +1035,7 @@ void LevelSolver::initialize() {
 }
 
 void LevelSolver::build_classes() {
-  const bool verbose_bc = std::getenv("HYMLS_MI_VERBOSE") != nullptr && level_ == 0;
+  const bool verbose_bc = std::getenv("HYMLS_MI_VERBOSE") != nullptr && (level_ == 0 || std::atoi(std::getenv("HYMLS_MI_VERBOSE")) >= 2);
   double t_bc = wall();
   auto lap_bc = [&](const char* what) {
     if (!verbose_bc) return;
@@ -1883,6 +1884,7 @@ void LevelSolver::set_values(const vvec& val) {
 // the reduced matrix of all ranks: every rank contributes the rows it owns; rows in rank order,
 // columns turned into global row numbers and sorted.  On one rank this is just red_.
 const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
+  FineLap fine;
   if (!glob_ready_) {
     ivec my_gids(red_.n);
     if (direct_schur_) for (int k = 0; k < n2_; k++) my_gids[k] = gids_[sep_row_[k]];
@@ -1896,6 +1898,7 @@ const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
     ivec len = comm_->allgather(my_len);
     cvec colg = comm_->allgather(red_.col);
     if (tvn) glob_tv_ = comm_->allgather(*tvn);
+    fine("(reduced) gather of gids / lengths / columns");
     {
       // clusters of the rows = the subdomains that list the node (the last-level direct solver dissects along them);
       // every rank contributes the lists of its rows and the centres of its subdomains, so that a sharded run orders
@@ -1916,6 +1919,7 @@ const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
       glob_sd_center_.assign(sd_center_.size(), 0);
       for (size_t t = 0; t + 3 < ctr.size(); t += 4) for (int a = 0; a < 3; a++) glob_sd_center_[3 * (size_t)ctr[t] + a] = ctr[t + 1 + a];
     }
+    fine("(reduced) clusters of the rows");
     const int64_t N = (int64_t)glob_gids_.size();
     HYMLS_CHECK(N < (int64_t)1 << 31, -2, "reduced matrix too large for 32-bit row numbers");
     ivec row_of(ngid_, -1);     // gid -> global row
@@ -1939,6 +1943,7 @@ const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
       for (size_t k = 0; k < row.size(); k++) { glob_.col[glob_.rowptr[i] + k] = row[k].first; glob_perm_[row[k].second] = glob_.rowptr[i] + (int64_t)k; }
     });
     HYMLS_CHECK(missing == 0, -3, "reduced matrix refers to a node nobody owns");
+    fine("(reduced) global columns, sorted rows");
     glob_.val.resize(glob_.col.size());
     glob_ready_ = true;
   }
@@ -1950,6 +1955,7 @@ const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
     HYMLS_CHECK(vals.size() == glob_.val.size(), -3, "reduced matrix changed its pattern between two Compute calls");
     parallel_for((int64_t)vals.size(), [&](int64_t e) { glob_.val[glob_perm_[e]] = vals[e]; }, 1 << 16);
   }
+  fine("(reduced) values into place");
   row_gids = glob_gids_;
   return glob_;
 }
@@ -2139,18 +2145,24 @@ void LevelSolver::compute() {
   const Csr& G = assemble_reduced(next_gids, &tvn);
   Csr& R = next_R_;
   drop_by_value(G, SMALL_ENTRY, 0, R);
+  { FineLap f2; f2.t = t0; f2("(reduced) assemble + drop, total"); }
   lap("reduced matrix (host)");
   if (level_ + 1 < p_.levels) {
     next_is_direct_ = false;
     if (next_level_ && next_pattern_key_rowptr_ == R.rowptr && next_pattern_key_col_ == R.col) {
       next_level_->swap_values(R.val);   // (sharded: the next level keeps the rows it needs; R keeps a buffer of the right size)
     } else {
+      FineLap fnl;
       next_pattern_key_rowptr_ = R.rowptr; next_pattern_key_col_ = R.col;
+      fnl("(next level) pattern key copy");
       next_level_ = new LevelSolver(p_.next_level(), level_ + 1, ngid_, comm_);
       next_.reset(next_level_);
       next_level_->set_rows(R, next_gids, glob_tv_, R.n);
+      fnl("(next level) set_rows");
       next_level_->initialize();
+      fnl("(next level) initialize");
       build_handoff(next_level_->owned_gids());
+      fnl("(next level) hand-off");
     }
     next_level_->profiling = false;  // phases are reported for the top level only
     lap("next level initialize");

@@ -264,13 +264,15 @@ ClassPlan analyse_class(const LocalPattern& lp, int leaf_size, int max_width, in
   });
   // a velocity block without couplings of its own (Darcy: A = a I, the velocities only meet through their pressures) fills
   // much less than its dense supernodes hold: small leaves keep the padding down -- measured on Darcy3D 256^3: 15.4 instead
-  // of 22.8 GB of panels per launch and 5.3 instead of 6.3 ms (profiles/r03_g_leaf_size_sweep.txt); with velocity
+  // of 22.8 GB of panels per launch and 5.3 instead of 6.3 ms at leaf 8 (profiles/r03_g_leaf_size_sweep.txt); leaves of
+  // 4 / 6 / 8 / 12 / 16: 19.4 / 18.0 / 17.6 / 17.4 / 17.6 ms per ApplyInverse (gpurun_out/r3ak): 12.  With velocity
   // couplings (Stokes) the larger leaves win, see LevelSolver::build_classes
   bool diagonal_a = nI > 0;
   for (int i = 0; i < nI && diagonal_a; i++) if (!vadj[i].empty()) diagonal_a = false;
   bool any_p = false;
   for (int i = 0; i < nI && !any_p; i++) any_p = lp.zero_diag[i] != 0;
-  if (diagonal_a && any_p) leaf_size = std::min(leaf_size, 8);
+  static const int leaf_diag = std::getenv("HYMLS_MI_LEAF_SIZE_DIAG") ? std::max(1, std::atoi(std::getenv("HYMLS_MI_LEAF_SIZE_DIAG"))) : 12;
+  if (diagonal_a && any_p) leaf_size = std::min(leaf_size, leaf_diag);
   // B B^T: the V-nodes of one pressure are connected to each other; row a collects through its own pressures (pv[a])
   rows_for(nI, [&](int64_t a) {
     if (lp.zero_diag[a]) return;

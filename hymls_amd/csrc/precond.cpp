@@ -1375,7 +1375,15 @@ void LevelSolver::build_classes() {
   }
   lap_bc("entry source lists");
   // ---- pass 2: symbolic analysis of every class (independent: in parallel)
-  parallel_for((int64_t)(cls_.size() - first_new), [&](int64_t k) {
+  // (the classes of a coarser level differ in size by an order of magnitude: the threads take them from a counter, largest first)
+  const int64_t ncls_new = (int64_t)(cls_.size() - first_new);
+  std::vector<int64_t> by_size((size_t)ncls_new);
+  std::iota(by_size.begin(), by_size.end(), 0);
+  std::stable_sort(by_size.begin(), by_size.end(), [&](int64_t a, int64_t b) { return cls_[first_new + a]->pat.col.size() > cls_[first_new + b]->pat.col.size(); });
+  std::atomic<int64_t> next_cls{0};
+  parallel_for(std::min<int64_t>(ncls_new, 64), [&](int64_t) {
+    for (int64_t q = next_cls.fetch_add(1); q < ncls_new; q = next_cls.fetch_add(1)) {
+    const int64_t k = by_size[(size_t)q];
     Cls& C = *cls_[first_new + k];
     // leaf size of the nested dissection: the finest level (LDS-fused solve, one workgroup walks the whole tree) is fastest at
     // 24 -- smaller leaves store up to 26 % fewer panel entries but add tree levels, each a barrier-bound step of the
@@ -1384,6 +1392,7 @@ void LevelSolver::build_classes() {
     static const int leaf0 = std::getenv("HYMLS_MI_LEAF_SIZE") ? std::atoi(std::getenv("HYMLS_MI_LEAF_SIZE")) : LEAF_SIZE;
     static const int leaf1 = std::getenv("HYMLS_MI_LEAF_SIZE_UPPER") ? std::atoi(std::getenv("HYMLS_MI_LEAF_SIZE_UPPER")) : LEAF_SIZE_UPPER;
     C.lu.plan = analyse_class(C.pat, level_ == 0 ? leaf0 : leaf1, MAX_WIDTH);
+    }
   }, 1);
   lap_bc("symbolic analysis");
   // ---- pass 3: interior numbering in elimination order, subdomain by subdomain
@@ -1896,7 +1905,9 @@ const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
     glob_row_off_.assign(1, 0);
     for (int64_t c : cnt) glob_row_off_.push_back(glob_row_off_.back() + c);
     ivec len = comm_->allgather(my_len);
-    cvec colg = comm_->allgather(red_.col);
+    cvec colg_all;
+    if (comm_->distributed()) colg_all = comm_->allgather(red_.col);
+    const cvec& colg = comm_->distributed() ? colg_all : red_.col;      // (one rank: no copy of 0.3 G columns)
     if (tvn) glob_tv_ = comm_->allgather(*tvn);
     fine("(reduced) gather of gids / lengths / columns");
     {
@@ -2149,11 +2160,14 @@ void LevelSolver::compute() {
   lap("reduced matrix (host)");
   if (level_ + 1 < p_.levels) {
     next_is_direct_ = false;
-    if (next_level_ && next_pattern_key_rowptr_ == R.rowptr && next_pattern_key_col_ == R.col) {
+    if (next_level_ && next_pattern_key_rowptr_.size() == R.rowptr.size() && next_pattern_key_col_.size() == R.col.size() &&
+        parallel_equal(next_pattern_key_rowptr_.data(), R.rowptr.data(), R.rowptr.size() * sizeof(int32_t)) &&
+        parallel_equal(next_pattern_key_col_.data(), R.col.data(), R.col.size() * sizeof(int32_t))) {
       next_level_->swap_values(R.val);   // (sharded: the next level keeps the rows it needs; R keeps a buffer of the right size)
     } else {
       FineLap fnl;
-      next_pattern_key_rowptr_ = R.rowptr; next_pattern_key_col_ = R.col;
+      parallel_assign(next_pattern_key_rowptr_, R.rowptr.data(), R.rowptr.size());
+      parallel_assign(next_pattern_key_col_, R.col.data(), R.col.size());
       fnl("(next level) pattern key copy");
       next_level_ = new LevelSolver(p_.next_level(), level_ + 1, ngid_, comm_);
       next_.reset(next_level_);

@@ -1156,7 +1156,11 @@ void LevelSolver::build_classes() {
     const int nI = (int)S.interior.size();
     ext.clear();
     ext.reserve(nI + S.num_sep());
-    for (int32_t g : S.interior) ext.push_back(g2l_[g]);
+    // (the look-ups below run at memory latency: the lines a few nodes ahead are requested early)
+    for (int i = 0; i < nI; i++) {
+      if (i + 16 < nI) __builtin_prefetch(&g2l_[S.interior[i + 16]]);
+      ext.push_back(g2l_[S.interior[i]]);
+    }
     SigMix m;
     m.add((uint64_t)nI); m.add((uint64_t)S.num_sep()); m.add((uint64_t)S.groups.size());
     for (auto& g : S.groups) {
@@ -1168,7 +1172,10 @@ void LevelSolver::build_classes() {
     const int ne = (int)ext.size();
     for (int i = 0; i < ne; i++) if (!(ext[i] >= 0 && ext[i] < nrows_)) return false;     // (the full build reports what is wrong)
     const int32_t e0 = ext[0];
-    for (int i = 0; i < ne; i++) { m.add((uint64_t)(uint32_t)(ext[i] - e0)); m.add(rowh[(size_t)ext[i]]); }
+    for (int i = 0; i < ne; i++) {
+      if (i + 16 < ne) { __builtin_prefetch(&rowh[(size_t)ext[i + 16]]); if (i + 16 >= nI) __builtin_prefetch(&pos2_[ext[i + 16]]); }
+      m.add((uint64_t)(uint32_t)(ext[i] - e0)); m.add(rowh[(size_t)ext[i]]);
+    }
     for (int i = nI; i < ne; i++) {
       const int k = pos2_[ext[i]];
       if (k < 0) return false;

@@ -681,3 +681,27 @@ def test_partition_matches_oracle_gpu(gpu_lib, eq, n, sx, part):
         for gi, (typ, owned, nodes) in enumerate(groups):
             assert typ == hm.groups[sd][gi][0] and np.array_equal(nodes, hm.groups[sd][gi][1])
             assert owned == (gi in hm.owned[sd])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eq,n,sx,levels,cx,part", [("Laplace", 24, 4, 2, 2, "Cartesian"), ("Stokes-C", 32, 8, 1, -1, "Skew Cartesian")])
+def test_device_built_setup_tables_equal_the_host_built_ones(gpu_lib, monkeypatch, eq, n, sx, levels, cx, part):
+    """Round 3 moved table construction of Initialize to the device: the members' entry source lists (k_member_sources), the
+    A12 / A21 blocks (k_offdiag), the pull tables of the reduced matrix (k_build_pull_tables), and classes are found by
+    signature.  HYMLS_MI_HOST_SOURCE_LISTS builds the source lists on the host and switches the signature shortcut off,
+    HYMLS_MI_VERIFY_CLASSES builds every pattern and compares: same bits in all three."""
+    import hymls_amd
+    A, tv = problem(eq, n)
+    b = np.random.default_rng(21).uniform(-1, 1, A.shape[0])
+    prm = xml_params(eq, n, sx, levels, cx, part)
+    out = []
+    for env in ({}, {"HYMLS_MI_HOST_SOURCE_LISTS": "1"}, {"HYMLS_MI_VERIFY_CLASSES": "1"}):
+        for k in ("HYMLS_MI_HOST_SOURCE_LISTS", "HYMLS_MI_VERIFY_CLASSES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        P = hymls_amd.Preconditioner(A, prm, testVector=tv, lib=gpu_lib)
+        assert P.Initialize() == 0 and P.Compute() == 0
+        out.append(P.ApplyInverse(b))
+        P.close()
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])

@@ -43,7 +43,14 @@ constexpr int MAX_WIDTH = 256;
 constexpr int MAX_WIDTH_COARSE = 256;  // wider supernodes take the piece-wise big-front path
 constexpr int LEAF_SIZE_COARSE = 512; // last-level solver (measured on configs[1], 216 k unknowns, gpurun_out/r3aj + r3ak: coarse phase 2.40 ms at 64,
                                       // 2.29 / 2.17 / 2.14 / 2.00 / 2.11 ms at 32 / 128 / 256 / 512 / 1024; the numeric Compute 0.98 -> 1.07 s)
-constexpr int64_t SCRATCH_BUDGET = 1LL << 30;  // doubles (8 GiB) of frontal scratch per pass
+// doubles of frontal scratch per factorisation pass: 8 GiB (HYMLS_MI_SCRATCH_GIB: other values).  Measured at 256^3
+// (gpurun_out/r3ar): recompute 2.69 - 2.81 s at 8 GiB, 2.92 - 2.99 s at 4 GiB, 4.1 s at 2 GiB (smaller batches per launch);
+// the first Compute, which allocates the arenas, 6.1 - 7.2 / 5.9 - 6.1 / 6.9 s.
+static const int64_t SCRATCH_BUDGET = [] {
+  const char* e = std::getenv("HYMLS_MI_SCRATCH_GIB");
+  const double gib = e ? std::max(0.25, std::atof(e)) : 8.0;
+  return (int64_t)(gib * (double)(1LL << 27));
+}();
 
 }  // namespace
 

@@ -757,8 +757,6 @@ void LevelSolver::partition(const ivec* level_gids) {
   if (level_gids) { present.assign(ngid_, 0); for (int32_t g : *level_gids) present[g] = 1; }
   sd_rank_.assign(nsd, 0);
   std::vector<char> cand;
-  HYMLS_CHECK(!(dist && (p_.perio[0] || p_.perio[1] || p_.perio[2])), -99,
-              "periodic grids are not implemented for sharded handles (the halo of a rank's box does not wrap around)");
   if (dist) {
     cand.assign(nsd, 0);
     const int bx = (p_.nx + comm_->px - 1) / comm_->px, by = (p_.ny + comm_->py - 1) / comm_->py,
@@ -773,8 +771,13 @@ void LevelSolver::partition(const ivec* level_gids) {
       const int cx = std::min(std::max(x, 0), p_.nx - 1), cy = std::min(std::max(y, 0), p_.ny - 1),
                 cz = std::min(std::max(z, 0), p_.nz - 1);
       sd_rank_[s] = ((cz / bz) * comm_->py + cy / by) * comm_->px + cx / bx;
-      cand[s] = nsd <= all_below || (x >= rx * bx - mx && x < (rx + 1) * bx + mx && y >= ry * by - my && y < (ry + 1) * by + my &&
-                                z >= rz * bz - mz && z < (rz + 1) * bz + mz);
+      // (a periodic direction: the window around the rank's box wraps around the grid)
+      auto near = [](int v, int lo, int hi, int n, bool per) {
+        return (v >= lo && v < hi) || (per && ((v + n >= lo && v + n < hi) || (v - n >= lo && v - n < hi)));
+      };
+      cand[s] = nsd <= all_below || (near(x, rx * bx - mx, (rx + 1) * bx + mx, p_.nx, p_.perio[0]) &&
+                                     near(y, ry * by - my, (ry + 1) * by + my, p_.ny, p_.perio[1]) &&
+                                     near(z, rz * bz - mz, (rz + 1) * bz + mz, p_.nz, p_.perio[2]));
     }
   }
   hm_ = build_hiermap(p_, level_gids ? &present : nullptr, dist ? &cand : nullptr);

@@ -50,6 +50,11 @@ def main():
     if cx > 0:
         prec["Coarsening Factor"] = cx
     prm = {"Problem": {"Equations": eq, "Dimension": 3, "nx": nx, "ny": ny, "nz": nz}, "Preconditioner": prec}
+    # HYMLS_TEST_PERIODIC=xyz letters: periodic directions (GaleriExt periodic matrices, wrap-around partitioner)
+    per = tuple(ax in os.environ.get("HYMLS_TEST_PERIODIC", "") for ax in "xyz")
+    for ax, on in zip("xyz", per):
+        if on:
+            prm["Problem"]["%s-periodic" % ax] = True
     a = float(nx * nx)
     if mode == "gpu-rccl":
         from hymls_amd.dist import RcclComm
@@ -60,7 +65,10 @@ def main():
                                  device=int(os.environ.get("LOCAL_RANK", "0")) if mode in ("gpu-nccl", "gpu-rccl") else 0)
     assert P.CommSelfTest() == 0, "transport self-test failed"
     req = P.RequiredRows()
-    rows = hymls_amd.generate_rows(eq, nx, ny, nz, req, a=a, lib=lib)
+    if any(per):
+        rows = hymls_amd.generate_problem("Stokes" if eq != "Laplace" else "Laplace", nx, ny, nz, a=a, gids=req, lib=lib, periodic=per)
+    else:
+        rows = hymls_amd.generate_rows(eq, nx, ny, nz, req, a=a, lib=lib)
     P.SetMatrixRows(req, rows)
     P.SetTestVector(hymls_amd.generate_testvector_rows(req, *rows))
     P.Initialize()
@@ -110,7 +118,10 @@ def main():
                 xsg[o] = xsl
             if xbl is not None:
                 xbg[o] = xbl
-        K = hymls_amd.generate_matrix(eq, nx, ny, nz, a=a, lib=lib)
+        if any(per):
+            K = hymls_amd.generate_problem("Stokes" if eq != "Laplace" else "Laplace", nx, ny, nz, a=a, lib=lib, periodic=per)
+        else:
+            K = hymls_amd.generate_matrix(eq, nx, ny, nz, a=a, lib=lib)
         tv = hymls_amd.generate_testvector(*K, lib=lib)
         P0 = hymls_amd.Preconditioner(K, prm, testVector=tv, lib=lib)
         P0.Compute()

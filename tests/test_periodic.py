@@ -206,27 +206,42 @@ def test_stokes4_3d_xml_through_the_driver(hostsim_lib):
     assert out["relative_residual"] <= 5e-11 and out["relative_error"] <= 5e-11
 
 
-def test_sharded_periodic_is_refused_not_wrong(hostsim_lib):
-    """documented gap: a sharded handle refuses periodic grids with -99 instead of building a halo that does not wrap"""
-    from test_sharded import run_worker  # noqa: F401  (the gloo worker is not needed: one forced rank is enough)
-    import subprocess, sys, textwrap
-    code = textwrap.dedent("""
-        import os, sys
-        sys.path.insert(0, %r)
-        os.environ["HYMLS_MI_FORCE_SHARDED"] = "1"; os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29641"
-        os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"
-        import torch.distributed as dist, hymls_amd
-        from hymls_amd.dist import TorchComm
-        dist.init_process_group(backend="gloo")
-        lib = hymls_amd.load_library(%r)
-        prm = {"Problem": {"Equations": "Stokes-C", "Dimension": 3, "nx": 8, "ny": 8, "nz": 8, "x-periodic": True},
-               "Preconditioner": {"Separator Length": 4, "Number of Levels": 0, "Partitioner": "Skew Cartesian"}}
-        P = hymls_amd.Preconditioner(None, prm, lib=lib, comm=TorchComm("cpu"), rank_grid=(1, 1, 1))
-        try:
-            P.RequiredRows()
-            print("NOT REFUSED")
-        except hymls_amd.HymlsError as e:
-            print("CODE", e.code)
-    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim", "libhymls_mi_hostsim.so")))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert "CODE -99" in r.stdout, r.stdout + r.stderr
+@pytest.mark.parametrize("world,args,env", [
+    (2, ("Stokes-C", 16, 8, 8, 4, 1, -1, "Skew Cartesian"), {}),
+    (4, ("Stokes-C", 16, 16, 8, 4, 1, -1, "Skew Cartesian"), {}),
+    (2, ("Stokes-C", 32, 16, 16, 4, 1, -1, "Skew Cartesian"), {"HYMLS_MI_HALO_ALL_BELOW": "0"}),
+])
+def test_sharded_x_periodic_matches_one_rank(hostsim_lib, world, args, env):
+    """a sharded handle on a periodic grid (x-periodic channel: no-slip walls in y and z, the pressure pinned as usual): the
+    subdomains at the far end of a rank's box share their separators with the subdomains at x = 0 of another rank, the halo
+    wraps around -- also in the geometric prefilter of large grids (third case: HYMLS_MI_HALO_ALL_BELOW=0 forces it).  Same
+    ApplyInverse, same K x, same Krylov count as on one rank, which tests/test_periodic.py pins against the oracle."""
+    from test_sharded import run_worker
+    res = run_worker(world, args, "hostsim", 29700 + world + (10 if env else 0), env_extra=dict(env, HYMLS_TEST_PERIODIC="x"))
+    assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
+    assert res["rel_err"] < 1e-12 and res["matvec_err"] < 1e-13
+    assert abs(res["krylov_its_sharded"] - res["krylov_its_one_rank"]) <= 1 and res["krylov_residual"] < 1e-6
+
+
+@pytest.mark.parametrize("levels", [0, 1])
+def test_x_periodic_channel_matches_oracle(hostsim_lib, levels):
+    """one rank, periodic in x only (a solvable Stokes problem without a border): ApplyInverse against the oracle.  Periodic in
+    y or z with the default pressure pin is refused by oracle and product alike ("fix GID 3 not in matrix row map")."""
+    n, sx, per = 8, 4, (True, False, False)
+    A = galeri.stokes3d(n, n, n, perio=per)
+    tv = galeri.create_testvector(A)
+    P = hymls_amd.Preconditioner(A, xml(n, sx, levels, "Skew Cartesian", per), testVector=tv, lib=hostsim_lib)
+    P.Compute()
+    p = Params(nx=n, ny=n, nz=n, sx=sx, levels=levels, equations="Stokes-C", partitioner="Skew Cartesian", perio=per).finalize()
+    O = OraclePrec(A, p, testvector=tv)
+    O.compute()
+    b = np.random.default_rng(0).uniform(-1, 1, A.shape[0])
+    assert rel_diff(P.ApplyInverse(b), O.apply_inverse(b)) < 1e-10
+    per2 = (False, True, True)
+    A2 = galeri.stokes3d(n, n, n, perio=per2)
+    with pytest.raises(hymls_amd.HymlsError) as e:
+        hymls_amd.Preconditioner(A2, xml(n, sx, levels, "Skew Cartesian", per2), testVector=galeri.create_testvector(A2), lib=hostsim_lib).Compute()
+    assert e.value.code == -2 and "fix GID" in str(e.value)
+    with pytest.raises(RuntimeError, match="fix GID"):
+        OraclePrec(A2, Params(nx=n, ny=n, nz=n, sx=sx, levels=levels, equations="Stokes-C", partitioner="Skew Cartesian", perio=per2).finalize(),
+                   testvector=galeri.create_testvector(A2)).compute()

@@ -194,6 +194,17 @@ def test_sharded_matches_single_gpu(gpu_lib, world, args):
 
 
 @pytest.mark.gpu
+def test_sharded_x_periodic_matches_single_gpu(gpu_lib):
+    """the same on a periodic grid (x-periodic channel): the halo of a rank's box wraps around
+    (tests/test_periodic.py::test_sharded_x_periodic_matches_one_rank is the CPU twin)"""
+    from test_sharded import run_worker
+    res = run_worker(2, ("Stokes-C", 32, 16, 16, 8, 1, -1, "Skew Cartesian"), "gpu", 29548, timeout=900, env_extra={"HYMLS_TEST_PERIODIC": "x"})
+    assert res["cover_ok"] and res["levels"] == res["levels_sharded"]
+    assert res["rel_err"] < 1e-10 and res["matvec_err"] < 1e-13
+    assert res["repeat_diff"] == 0.0 and res["recompute_diff"] < 1e-12
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("small_rows", ["256", "16"])
 def test_merged_level_solve_path_gpu(gpu_lib, monkeypatch, small_rows):
     """k_lvl_fwd / k_lvl_bwd (solve of subdomains too large for the fused kernel), forced on a small problem:

@@ -38,7 +38,7 @@ inline void gid_coord(const Params& p, int32_t gid, int32_t* c) {
 }
 
 constexpr int LEAF_SIZE = 24;
-constexpr int LEAF_SIZE_UPPER = 64;   // levels >= 1 (measured at 256^3: coarse phase 6.2 -> 5.7 ms; 48: 5.8, 96: 5.6)
+constexpr int LEAF_SIZE_UPPER = 64;   // levels >= 1 (measured at 256^3: coarse phase 6.2 -> 5.7 ms; 48: 5.8, 96: 5.6; end of round 3, gpurun_out/r3at: 64 / 96 / 128 / 192 = 5.58 / 5.52 / 5.65 / 5.83 ms)
 constexpr int MAX_WIDTH = 256;
 constexpr int MAX_WIDTH_COARSE = 256;  // wider supernodes take the piece-wise big-front path
 constexpr int LEAF_SIZE_COARSE = 512; // last-level solver (measured on configs[1], 216 k unknowns, gpurun_out/r3aj + r3ak: coarse phase 2.40 ms at 64,

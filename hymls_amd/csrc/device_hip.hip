@@ -18,6 +18,10 @@
 //     k_factor_level             multifrontal front: assemble, LU of the pivot block, triangular inverses, panel
 //                                products and the Schur update as workgroup-level tiled GEMMs (LDS staged)
 //     k_big_* / k_gemm_f64       wide supernodes spread over many workgroups; FP64 MFMA GEMMs with triangular masks
+//     k_gemm_f64_big             the same products with 128 x 128 tiles and a register prefetch of the next K slab (rank >= 256
+//                                updates, or rank >= 64 when the launch fills the chip); factor_big_front works in outer blocks
+//                                of 512 columns so that the trailing matrix is read and written once per rank-512 update;
+//                                panel_trmm: the panel products of a pivot piece in place on the same kernels
 //     k_big_pivot_blk            pivot pieces (<= 128 x 128): 32 x 32 diagonal blocks factored and inverted in registers,
 //                                everything else as MFMA tile products between LDS operands (k_big_pivot: scalar variant)
 //     k_repack                   packed L-side panels for the classes of the fused solve
@@ -25,6 +29,10 @@
 //     k_gj_* / k_dense_invert    separator blocks: blocked Gauss-Jordan with partial pivoting (32 pivots per panel in registers,
 //                                rank-32 update on the matrix cores) / per-block Gauss-Jordan in LDS or global memory
 //     k_pull_sum*                deterministic assembly of the kept Schur entries
+//   tables of Initialize built on the device (integers):
+//     k_member_sources           entry of the level matrix behind every entry of a member's extended local CSR (binary search)
+//     k_offdiag<count / fill>    the blocks A12 / A21 cut out of the level matrix
+//     k_build_pull_tables        pull pointers / indices of the reduced matrix from its sorted keys
 //     k_solve_transposed, k_dot  bordered systems
 #include <hip/hip_runtime.h>
 #include <type_traits>

@@ -1911,7 +1911,10 @@ void LevelSolver::set_values(const vvec& val) {
 
 // the reduced matrix of all ranks: every rank contributes the rows it owns; rows in rank order,
 // columns turned into global row numbers and sorted.  On one rank this is just red_.
-const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
+// the pattern part of assemble_reduced: gathered gids, clusters, global columns and the permutation of the values.  Depends on
+// Initialize-time data only, so that the first Compute of an unsharded handle runs it on a helper thread next to the
+// factorisation (compute()).
+void LevelSolver::prepare_reduced_pattern(const dvec* tvn) {
   FineLap fine;
   if (!glob_ready_) {
     ivec my_gids(red_.n);
@@ -1977,6 +1980,11 @@ const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
     glob_.val.resize(glob_.col.size());
     glob_ready_ = true;
   }
+}
+
+const Csr& LevelSolver::assemble_reduced(ivec& row_gids, dvec* tvn) {
+  FineLap fine;
+  prepare_reduced_pattern(tvn);
   {
     // (one rank: no copy of the 0.2 G values of a 256^3 run)
     vvec gathered;
@@ -2024,6 +2032,17 @@ void LevelSolver::stream_plan(bool& side, int& chunk_streams) const {
 // (Measured and dropped, gpurun_out/r3ag: requesting the scratch arenas of the first Compute -- 6 - 8 GiB per stream, 1.4 s of
 // hipMalloc -- on helper threads during Initialize as well.  Together with the factor arrays that is 50 GiB for the driver to
 // clear, and every HIP call of the setup thread queues behind it: A12 / A21 0.46 -> 1.7 s, pull lists 0.63 -> 1.0 s.)
+// next test vector = V-sum part of H * testvector (reference src/HYMLS_SchurPreconditioner.cpp:569-573)
+void LevelSolver::next_test_vector(dvec& tvn) const {
+  const int ng = (int)vs_.size();
+  tvn.resize(ng);
+  for (int g = 0; g < ng; g++) {
+    double dot = 0;
+    for (int i = gptr_[g]; i < gptr_[g + 1]; i++) dot += otw_[i] * tv_[sep_row_[i]];
+    tvn[g] = 2.0 * otw_[gptr_[g]] * dot - tv_[sep_row_[gptr_[g]]];
+  }
+}
+
 void LevelSolver::compute() {
   HYMLS_CHECK(initialized_, -1, "level not initialized");
   dev::Range range("Preconditioner", level_ + 1, "Compute");
@@ -2049,6 +2068,16 @@ void LevelSolver::compute() {
   stream_plan(side, chunk_streams);
   struct MainStreamGuard { ~MainStreamGuard() { try { dev::use_stream(0); } catch (...) {} } } back_to_main;   // also when a launch throws
   for (auto& cp : cls_) dev::zero(cp->lu.batch.flag, 4 * sizeof(int32_t));   // (on the main stream, before any side stream starts)
+  // First Compute of an unsharded handle: the pattern of the reduced matrix (0.5 s of host work at 256^3) is put together on a
+  // helper thread while this thread launches the factorisation.  (Sharded: the gathers are collective, they stay in line.)
+  dvec tvn_early;
+  std::thread pattern_thread;
+  std::exception_ptr pattern_err;
+  struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } pattern_join{pattern_thread};
+  if (!glob_ready_ && !direct_schur_ && !comm_->distributed() && !std::getenv("HYMLS_MI_NO_PATTERN_THREAD")) {
+    next_test_vector(tvn_early);
+    pattern_thread = std::thread([&] { try { prepare_reduced_pattern(&tvn_early); } catch (...) { pattern_err = std::current_exception(); } });
+  }
   // (the subdomain factorisations and what is kept of the Schur complement come out of the same launches here: one range)
   auto range_mb = std::make_unique<dev::Range>("MatrixBlock", level_ + 1, "Compute");
   if (side || chunk_streams) dev::fork_streams();
@@ -2160,16 +2189,11 @@ void LevelSolver::compute() {
                   " (3D Stokes-C needs the Skew Cartesian partitioner: isolated pressure 'tubes' on subdomain edges)");
   // ---- next level (ComputeNextLevel, reference src/HYMLS_SchurPreconditioner.cpp:520-629)
   const int ng = (int)vs_.size();
+  (void)ng;
+  if (pattern_thread.joinable()) pattern_thread.join();
+  if (pattern_err) std::rethrow_exception(pattern_err);
   dvec tvn;
-  if (!glob_ready_) {
-    // next test vector = V-sum part of H * testvector (:569-573)
-    tvn.resize(ng);
-    for (int g = 0; g < ng; g++) {
-      double dot = 0;
-      for (int i = gptr_[g]; i < gptr_[g + 1]; i++) dot += otw_[i] * tv_[sep_row_[i]];
-      tvn[g] = 2.0 * otw_[gptr_[g]] * dot - tv_[sep_row_[gptr_[g]]];
-    }
-  }
+  if (!glob_ready_) next_test_vector(tvn);
   lap("pull + separator blocks");
   auto range_nl = std::make_unique<dev::Range>("SchurPreconditioner", level_ + 1, "ComputeNextLevel");
   const Csr& G = assemble_reduced(next_gids, &tvn);

@@ -203,6 +203,8 @@ class LevelSolver : public Operator {
   // ghost columns; on one rank simply the whole matrix
   void set_rows(const Csr& K, const ivec& gids, const dvec& tv, int32_t nrows);
   void stream_plan(bool& side, int& chunk_streams) const;
+  void prepare_reduced_pattern(const dvec* tvn);
+  void next_test_vector(dvec& tvn) const;
   void initialize();
   void compute();                       // uses the host values of K (uploads them)
   void set_values(const vvec& val);     // SetMatrix with unchanged pattern

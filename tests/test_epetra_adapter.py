@@ -74,10 +74,10 @@ def build_mpi(tmp_path, libdir, libname, what):
     return exe
 
 
-def run_mpi(exe, ranks, transport, marker, env_extra=None):
+def run_mpi(exe, ranks, transport, marker, env_extra=None, extra_args=()):
     env = dict(os.environ, OMP_NUM_THREADS="1", HYMLS_MI_HOST_THREADS="2")
     env.update(env_extra or {})
-    out = subprocess.run([MPIEXEC, "-n", str(ranks), exe, transport], capture_output=True, text=True, timeout=1200, env=env)
+    out = subprocess.run([MPIEXEC, "-n", str(ranks), exe, transport] + list(extra_args), capture_output=True, text=True, timeout=1200, env=env)
     assert out.returncode == 0 and marker in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
     return out.stdout
 
@@ -91,8 +91,9 @@ def test_distributed_adapter_under_mpiexec(tmp_path, hostsim_lib, ranks):
     Ifpack_Preconditioner* == the one-rank result to 1e-12; a CG loop that only sees Epetra_Operator converges in the same
     number of iterations; Stokes (Skew) + border.  Reference: src/HYMLS_Preconditioner.hpp:56-84,182-186, src/main.cpp:50-67."""
     exe = build_mpi(tmp_path, os.path.join(ROOT, "tests", "hostsim"), "hymls_mi_hostsim", "adapter_driver_mpi")
-    out = run_mpi(exe, ranks, "MPI", "ADAPTER_MPI_OK")
+    out = run_mpi(exe, ranks, "MPI", "ADAPTER_MPI_OK", extra_args=("periodic",))
     assert "%d ranks (MPI)" % ranks in out and "preconditioned CG through Epetra_Operator" in out
+    assert "x-periodic Stokes channel sharded vs one rank" in out       # (periodic grid through the distributed adapter)
 
 
 @needs_mpi
